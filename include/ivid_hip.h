@@ -1,0 +1,133 @@
+/* ivid_hip.h — C ABI of libivid_hip.so, the MI355X (gfx950) kernels behind ivid's sampling hot path.
+ *
+ * The reference (JeffreyXiang/ivid) has no C/FFI boundary: its plug-in boundary is a set of Python
+ * call signatures.  This header is the boundary a maintainer binds from Python
+ * (ctypes): every entry point below replaces the torch/cuDNN/OpenGL call sites
+ * cited next to it.  Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named host_*;
+ *   - the caller (torch) owns every buffer; the library allocates nothing that crosses the ABI
+ *     (it owns one 256-byte zero page and hipGraph handles);
+ *   - every kernel is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises;
+ *   - return value 0 = ok, nonzero = error; ivid_last_error() gives the message; never aborts;
+ *   - activations inside the UNet are NHWC ("pixel-major") of dtype IVID_F32 (parity mode, exact
+ *     fp32 MFMA) or IVID_BF16 (perf mode, bf16 MFMA with fp32 accumulate); the model boundary is
+ *     fp32 NCHW exactly like the reference (adm.py:557,565-566).
+ */
+#ifndef IVID_HIP_H
+#define IVID_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVID_F32 0
+#define IVID_BF16 1
+
+/* ---- runtime ---- */
+const char* ivid_last_error(void);
+int ivid_version(void);
+/* hipGraph capture of a launch sequence on `stream` (replaces ~300 eager launches per UNet forward). */
+int ivid_graph_begin(void* stream);
+int ivid_graph_end(void* stream, void** graph_exec_out);
+int ivid_graph_launch(void* graph_exec, void* stream);
+int ivid_graph_destroy(void* graph_exec);
+/* Timing of a stream region with HIP events (used by bench.py; torch.cuda.Event only sees torch's stream). */
+int ivid_event_create(void** ev_out);
+int ivid_event_record(void* ev, void* stream);
+int ivid_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+int ivid_event_destroy(void* ev);
+
+/* ---- convolution / linear: nn.Conv2d 3x3 pad1 (adm.py:160,182,369,486), nn.Conv2d 1x1 skip (adm.py:190),
+ *      nn.Conv1d k=1 qkv/proj_out (adm.py:275,278), nn.Linear (adm.py:176,359,361) ----
+ * out[n,y,x,co] = bias[co] + sum_{tap,c} cat(src0,src1)[n,y+dy,x+dx,c] * weight[co][tap][c]  (+ residual)
+ *   src0/src1 : NHWC [N,H,W,C0] / [N,H,W,C1] (C1 = 0, src1 = NULL when there is no skip concat,
+ *               adm.py:563 torch.cat is never materialised); C0, C1 multiples of 64 (bf16) / 32 (f32)
+ *   weight    : [Cout][taps][C0+C1], dtype as activations (repacked from [Cout,Cin,3,3] by the host)
+ *   bias      : fp32 [Cout] or NULL
+ *   res_mode  : 0 none; 1 add res[N,H,W,Cout]; 2 add nearest-x2-upsampled res[N,H/2,W/2,Cout];
+ *               3 add 2x2-avg-pooled res[N,2H,2W,Cout]  (ResBlock2d skip through x_upd, adm.py:203-208,222)
+ *   out_mode  : 0 NHWC dtype [N,H,W,Cout]; 1 fp32 NCHW [N,Cout,H,W] (final conv, adm.py:566)
+ *   tile_cfg  : 0 auto, 1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves */
+int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias,
+                void* out, const void* res, int res_mode, int out_mode, int N, int H, int W, int Cout, int taps,
+                int tile_cfg, void* stream);
+
+/* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
+ * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).
+ *   partial: fp32 [N][nchunks][C0+C1][2]; nchunks = ivid_gn_num_chunks(H*W). */
+int ivid_gn_num_chunks(int HW);
+int ivid_gn_partial(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int HW, float* partial,
+                    void* stream);
+/* Step 2: fold statistics, affine and FiLM into one per-(n,c) scale/offset:
+ *   y = x*a + b,  a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale) + shift
+ *   film: fp32 rows [N][film_stride]; scale = film[n][film_off + c], shift = film[n][film_off + C + c]
+ *   (torch.chunk(emb_out,2), adm.py:216) or NULL.  ab: fp32 [N][C][2]. */
+int ivid_gn_finalize(const float* partial, int nchunks, int N, int C, int HW, int groups, float eps,
+                     const float* gamma, const float* beta, const float* film, int film_stride, int film_off,
+                     float* ab, void* stream);
+/* Step 3: out = act(x*a+b) with optional resampling folded in (adm.py:203-208):
+ *   resample 0: same size; 1: nearest x2 upsample (out is 2H x 2W); 2: 2x2 average pool of the ACTIVATED
+ *   values (out is H/2 x W/2).  act: 0 identity (AttentionBlock.norm, adm.py:283), 1 SiLU.
+ *   H, W are the SOURCE spatial dims.  out: NHWC dtype [N,Ho,Wo,C0+C1] (concat materialised here). */
+int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, void* out, int N,
+                  int H, int W, int resample, int act, void* stream);
+
+/* ---- QKVAttention (adm.py:233-253), legacy per-head [q|k|v] channel interleave ----
+ * qkv: NHWC [N,T,3*C] with channel = head*192 + {0..63 q, 64..127 k, 128..191 v}; out: [N,T,C], channel = head*64+d.
+ * softmax in fp32 (adm.py:251); scores scaled by 64^-1/2 overall (q*64^-1/4 . k*64^-1/4, adm.py:247-250). */
+int ivid_attention(int dtype, const void* qkv, void* out, int N, int T, int heads, void* stream);
+
+/* ---- embeddings: PosEncoding + label_emb with null-class mask (adm.py:30-33,545-555) ----
+ * pos[n][0..half) = cos(t[n]*freqs[k]), pos[n][half..2half) = sin(...)   (cos first, adm.py:32)
+ * cls[n][:] = classes? label_emb[max(c,0)] * (c>=0) : 0
+ * times/classes are int64 device arrays of length Bsrc, broadcast to N rows by n % Bsrc;
+ * null_from: rows n >= null_from use the null class (stacked classifier-free-guidance batch). */
+int ivid_embed_inputs(const int64_t* times, const int64_t* classes, int Bsrc, int N, int null_from,
+                      const float* freqs, int half, const float* label_emb, int emb_dim, float* pos, float* cls,
+                      void* stream);
+/* y = silu(x) elementwise on fp32 (emb_layers[0] / time_embed[2], adm.py:175,360). */
+int ivid_silu_f32(const float* x, float* y, long long n, void* stream);
+
+/* ---- model boundary layout changes ----
+ * fp32 NCHW [Bsrc,Cin,H,W] -> NHWC dtype [N,H,W,Cpad] (zero padded channels, batch replicated n % Bsrc). */
+int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Cpad, void* out,
+                      void* stream);
+
+/* ---- samplers (fp32 NCHW [B,4,H,W]) ----
+ * eps = (1+s)*eps_c - s*eps_u (classifier_free_guidance.py:39-42); eps_u may be NULL (s ignored). */
+typedef struct {
+  float sqrt_recip_ac;   /* sqrt(1/alpha_bar[t-1])           ddim.py:36 */
+  float sqrt_recipm1_ac; /* sqrt(1/alpha_bar[t-1]-1)         ddim.py:37 */
+  float sqrt_ac_prev;    /* sqrt(alpha_bar_prev[t_prev])     ddim.py:99 */
+  float dir_coef;        /* sqrt(1-alpha_bar_prev-sigma^2)   ddim.py:99 */
+  float sigma;           /* eta*...                          ddim.py:98 */
+  float nonzero;         /* t_prev != 0                      ddim.py:83 */
+  float cfg_strength;
+  float replace_rgb_w;   /* <0: disabled                     ddim.py:86-89 */
+  float replace_depth_w; /* <0: disabled                     ddim.py:90-92 */
+  float constrain_w;     /* <0: disabled                     ddim.py:93-95 */
+  int clip_denoised;
+} ivid_ddim_coef;
+/* One DDIM update (ddim.py:81-102).  rgb [B,3,H,W], rgb_mask [B,1,H,W], depth [B,1,H,W], depth_mask [B,1,H,W],
+ * convex [B,1,H,W] may be NULL when the matching weight is < 0; noise may be NULL when sigma == 0. */
+int ivid_ddim_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddim_coef* host_coef,
+                   const float* rgb, const float* rgb_mask, const float* depth, const float* depth_mask,
+                   const float* convex, const float* noise, float* x_prev, float* x0, int B, int HW, void* stream);
+typedef struct {
+  float sqrt_recip_ac, sqrt_recipm1_ac; /* ddpm.py:33-34 */
+  float coef1, coef2;                   /* posterior mean coefficients, ddpm.py:40-41 */
+  float std;                            /* exp(0.5*posterior_log_variance_clipped[t]) * (t != 0), ddpm.py:129-130 */
+  float cfg_strength;
+  int clip_denoised;
+} ivid_ddpm_coef;
+int ivid_ddpm_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddpm_coef* host_coef,
+                   const float* noise, float* x_prev, float* x0, int B, int HW, void* stream);
+/* InpaintCFG.make_cond_inputs (inpaint_cfg.py:24-49): out [B,10 or 9,H,W] =
+ * cat[x(4), mask_rgb(1, if given), y_rgb*m_rgb + n_rgb*(1-m_rgb) (3), y_d*m + n_d*(1-m) (1), mask(1)]. */
+int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const float* mask_rgb, const float* noise_rgb,
+                      const float* noise_depth, float* out, int B, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""ctypes binding of libivid_hip.so (include/ivid_hip.h).
+
+The HIP library is the product path: there is no CPU fallback.  Importing this module never
+needs a GPU (the symbols are only resolved), but every compute entry point raises if the
+library is missing or a launch fails.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libivid_hip.so")
+
+F32, BF16 = 0, 1
+
+vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_longlong, C.c_void_p
+
+
+class DdimCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "sqrt_recip_ac", "sqrt_recipm1_ac", "sqrt_ac_prev", "dir_coef", "sigma", "nonzero", "cfg_strength",
+        "replace_rgb_w", "replace_depth_w", "constrain_w")] + [("clip_denoised", C.c_int)]
+
+
+class DdpmCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "sqrt_recip_ac", "sqrt_recipm1_ac", "coef1", "coef2", "std", "cfg_strength")] + [("clip_denoised", C.c_int)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/ivid_hip.h
+SIGNATURES = {
+    "ivid_last_error": (C.c_char_p, []),
+    "ivid_version": (i32, []),
+    "ivid_graph_begin": (i32, [vp]),
+    "ivid_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "ivid_graph_launch": (i32, [vp, vp]),
+    "ivid_graph_destroy": (i32, [vp]),
+    "ivid_event_create": (i32, [C.POINTER(vp)]),
+    "ivid_event_record": (i32, [vp, vp]),
+    "ivid_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
+    "ivid_event_destroy": (i32, [vp]),
+    "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ivid_gn_num_chunks": (i32, [i32]),
+    "ivid_gn_partial": (i32, [i32, vp, i32, vp, i32, i32, i32, vp, vp]),
+    "ivid_gn_finalize": (i32, [vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, i32, i32, vp, vp]),
+    "ivid_gn_apply": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ivid_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),
+    "ivid_embed_inputs": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
+    "ivid_silu_f32": (i32, [vp, vp, i64, vp]),
+    "ivid_nchw_to_nhwc": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ivid_ddpm_step": (i32, [vp, vp, vp, C.POINTER(DdpmCoef), vp, vp, vp, i32, i32, vp]),
+    "ivid_inpaint_cond": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+}
+
+_lib = None
+
+
+class IvidHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IvidHipError(
+            f"{LIB_PATH} not found: build it with `python -m ivid_amd.build` (hipcc, gfx950). "
+            "ivid_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().ivid_last_error()
+        raise IvidHipError(f"{what}: {msg.decode() if msg else status}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

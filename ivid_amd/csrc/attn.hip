@@ -1,0 +1,233 @@
+// QKVAttention (adm.py:233-253) for the legacy [head][q|k|v][64] channel interleave, fused:
+//   S = (q*d^-1/4)(k*d^-1/4)^T  ->  softmax in fp32 (adm.py:251)  ->  a = P.V
+// Flash-style: no [T,T] score matrix ever reaches HBM (the reference materialises it twice).
+//
+// One workgroup = one (image n, head h, block of 32*NW queries); each wave owns 32 queries.
+// Per 64-row K/V tile:
+//   S^T[kv][q] = K . Q^T   (A operand = K rows from LDS, B operand = Q rows held in registers)
+//       -> in the 32x32 C/D layout every lane owns ONE query column (q = lane&31) and 16 of the
+//          32 kv rows, lane^32 owns the other 16: row max / row sum are 15 in-lane ops + one
+//          cross-half shuffle, and the running (m, l) and the O rescale are lane-local.
+//   O^T[d][q] += V^T . P^T (A operand = V^T fragments, B operand = P straight from the S^T
+//          accumulators: the MFMA k index is (lane half, element), the same kv permutation is
+//          applied to the V^T fragment, so no cross-lane movement of P is needed.)
+// bf16 mode: v_mfma_f32_32x32x16_bf16; V is transposed into LDS as Vt[d][kv] while staging.
+// fp32 mode: v_mfma_f32_32x32x2_f32 (exact); V stays [kv][d] (one float per lane per MFMA).
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int HD = 64;   // head dim (num_head_channels = 64 in every config)
+constexpr int KVB = 64;  // K/V rows per tile
+
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<__bf16> {
+  static constexpr int RB = 128;  // bytes per K row
+  static __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+};
+template <> struct AttnCfg<float> {
+  static constexpr int RB = 256;
+  static __device__ __forceinline__ int swz(int row) { return row & 15; }
+};
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const char* __restrict__ qkv, char* __restrict__ out, int T_,
+                                                       int heads) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  constexpr int NT = NW * 64;
+  constexpr int RB = AttnCfg<T>::RB;
+  constexpr int PPR = RB / 16;              // 16-byte pieces per row
+  constexpr int TILE_BYTES = KVB * RB;      // one K (or V) tile
+  constexpr int KPIECES = KVB * PPR;
+  constexpr int KK = HD * (int)sizeof(T) / 32;  // piece pairs along d: 4 (bf16) / 8 (fp32)
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+  char* sK = smem;
+  char* sV = smem + TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qblk = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  const int C = heads * HD;
+  const size_t rowstride = (size_t)3 * C * sizeof(T);  // bytes between tokens in qkv
+  const char* base = qkv + ((size_t)n * T_) * rowstride + (size_t)h * 3 * HD * sizeof(T);
+  const int fq = lane & 31, hf = lane >> 5;
+  const int q = qblk * (32 * NW) + wave * 32 + fq;
+
+  // Q fragments: B operand, row q, piece 2*kk+hf
+  vec_t qf[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const vec_t*)(base + (size_t)q * rowstride + (2 * kk + hf) * 16);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e): scores in the log2 domain
+
+  for (int kv0 = 0; kv0 < T_; kv0 += KVB) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K: swizzled source, lane-linear LDS image ----
+#pragma unroll
+    for (int i = 0; i < KPIECES / NT; ++i) {
+      const int p = i * NT + tid;
+      const int row = p / PPR, pos = p - row * PPR;
+      const int c = pos ^ AttnCfg<T>::swz(row);
+      glds16(base + (size_t)(kv0 + row) * rowstride + HD * sizeof(T) + c * 16, sK + (i * NT + wave * 64) * 16);
+    }
+    if constexpr (!IS_BF16) {
+      // ---- stage V as [kv][d] (fp32) ----
+#pragma unroll
+      for (int i = 0; i < KPIECES / NT; ++i) {
+        const int p = i * NT + tid;
+        const int row = p / PPR, pos = p - row * PPR;
+        glds16(base + (size_t)(kv0 + row) * rowstride + 2 * HD * sizeof(T) + pos * 16, sV + (i * NT + wave * 64) * 16);
+      }
+    } else {
+      // ---- stage V transposed: Vt[d][kv], 8-byte units XOR-swizzled by (d>>1)&15 ----
+#pragma unroll
+      for (int i = 0; i < KPIECES / NT; ++i) {
+        const int p = i * NT + tid;
+        const int kv = p / PPR, d0 = (p - kv * PPR) * 8;
+        const bf16x8 v = *(const bf16x8*)(base + (size_t)(kv0 + kv) * rowstride + 2 * HD * sizeof(T) + d0 * 2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int d = d0 + e;
+          *(__bf16*)(sV + d * 128 + (((kv >> 2) ^ ((d >> 1) & 15)) << 3) + (kv & 3) * 2) = v[e];
+        }
+      }
+    }
+    wait_vmcnt0();
+    __syncthreads();
+
+    // ---- S^T = K.Q^T for the two 32-row halves of the tile ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvh][r] = 0.f;
+      const int row = kvh * 32 + fq;
+      const int sw = AttnCfg<T>::swz(row);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const vec_t kf = *(const vec_t*)(sK + row * RB + (((2 * kk + hf) ^ sw) << 4));
+        if constexpr (IS_BF16) {
+          s[kvh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kvh], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[kvh] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[kk][j], s[kvh], 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax (per lane: one query, 32 of the 64 kv; lane^32 has the rest) ----
+    float mt = -1e30f;
+#pragma unroll
+    for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[kvh][r] *= sc;
+        mt = fmaxf(mt, s[kvh][r]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[kvh][r] = __builtin_amdgcn_exp2f(s[kvh][r] - m_new);
+        ps += s[kvh][r];
+      }
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ----
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          bf16x8 pf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kvh][8 * mm + e];
+          // element e of lane-half hf is kv = kvh*32 + 16*mm + 8*(e>>2) + 4*hf + (e&3)
+          const int u0 = (kvh * 32 + 16 * mm + 4 * hf) >> 2;  // 8-byte unit of e = 0..3; e = 4..7 is unit u0+2
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int d = dt * 32 + fq;
+            const int sw = (d >> 1) & 15;
+            const bf16x4 lo = *(const bf16x4*)(sV + d * 128 + ((u0 ^ sw) << 3));
+            const bf16x4 hi = *(const bf16x4*)(sV + d * 128 + (((u0 + 2) ^ sw) << 3));
+            bf16x8 vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              vf[e] = lo[e];
+              vf[4 + e] = hi[e];
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int kvh = 0; kvh < 2; ++kvh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kvh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const float vv = *(const float*)(sV + kv * 256 + (dt * 32 + fq) * 4);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kvh][r], o[dt], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- normalise and store: lane owns query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hf ----
+  const float inv = 1.0f / l_run;
+  char* orow = out + (((size_t)n * T_ + q) * C + (size_t)h * HD) * sizeof(T);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = dt * 32 + 8 * g + 4 * hf;
+      if constexpr (IS_BF16) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * g + e] * inv);
+        *(bf16x4*)(orow + d * 2) = w;
+      } else {
+        f32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = o[dt][4 * g + e] * inv;
+        *(f32x4*)(orow + d * 4) = w;
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int ivid_attention(int dtype, const void* qkv, void* out, int N, int T, int heads, void* stream) {
+  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("attention: bad dtype", hipSuccess);
+  if (T <= 0 || T % 64) return ivid_set_error("attention: T must be a multiple of 64", hipSuccess);
+  hipStream_t s = (hipStream_t)stream;
+  const bool four = (T % 128) == 0;
+  dim3 grid(T / (four ? 128 : 64), heads, N);
+#define LAUNCH(TT, NW) \
+  hipLaunchKernelGGL((attn_kernel<TT, NW>), grid, dim3(NW * 64), 0, s, (const char*)qkv, (char*)out, T, heads)
+  if (dtype == IVID_BF16) {
+    if (four) LAUNCH(__bf16, 4); else LAUNCH(__bf16, 2);
+  } else {
+    if (four) LAUNCH(float, 4); else LAUNCH(float, 2);
+  }
+#undef LAUNCH
+  return ivid_check_launch("attention");
+}

@@ -1,0 +1,339 @@
+// Implicit-GEMM convolution (3x3 pad 1 / 1x1 / Linear) on the CDNA4 matrix cores.
+//
+// Replaces every nn.Conv2d / nn.Conv1d(k=1) / nn.Linear call of the reference UNet
+// (/root/reference/diffusion/backbones/adm.py:160,182,190,275,278,359,361,176,369,486).
+//
+//   out[m][co] = bias[co] + sum_{tap,c} act[pixel(m)+tap][c] * w[co][tap][c]   (+ residual)
+//
+// GEMM view: M = N*H*W output pixels, N = Cout, K = taps*(C0+C1).  Both operands are
+// "K-contiguous rows": an A row is a pixel's channel vector (NHWC), a B row is one output
+// channel's [tap][cin] weights.  A K-step is 128 bytes of K (64 bf16 / 32 fp32) of ONE tap,
+// so the im2col gather is a per-lane source address into the NHWC tensor (or into a zero page
+// for padding) fed to global_load_lds (HBM/L2 -> LDS without touching VGPRs).
+//
+// LDS image per operand and stage: [rows][128 B], 16-byte pieces XOR-swizzled by
+// ((row>>1)&7) so that the ds_read_b128 of an MFMA fragment (32 rows x one piece column)
+// is bank-conflict free.  global_load_lds writes lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address and again on the fragment read (same involution).
+//
+// MFMA: perf mode  v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate),
+//       parity mode v_mfma_f32_32x32x2_f32  (exact fp32 == fmaf chain).
+// C/D layout (both): col = lane&31 (cout), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (pixel).
+//
+// Epilogue: accumulators -> per-wave LDS slab -> 16-byte coalesced NHWC stores with fused
+// bias, residual add (same / nearest-up x2 / avg-pool-down x2 of the residual source, i.e.
+// ResBlock2d's x_upd skip path, adm.py:203-208,222) or fp32 NCHW output for the final conv.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct ConvArgs {
+  const char* src0;
+  const char* src1;
+  const char* w;
+  const float* bias;
+  char* out;
+  const char* res;
+  const char* zero;
+  int C0, C1;
+  int N, H, W;
+  int Cout;
+  int taps;      // 1 or 9
+  int res_mode;  // 0 none, 1 same size, 2 residual is (H/2,W/2) nearest-up, 3 residual is (2H,2W) avg-pool
+  int out_mode;  // 0 NHWC T, 1 NCHW fp32
+  int M;
+  int ntiles_n;
+  int ntiles_total;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+  // one 16-byte piece per lane = 8 k-values; lanes 0-31 / 32-63 hold consecutive pieces.
+  static __device__ __forceinline__ void run(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // one 16-byte piece per lane = 4 k-values; MFMA j pairs k=j of the low-lane piece with k=j
+  // of the high-lane piece.  A and B use the same k permutation, so the sum is unchanged.
+  static __device__ __forceinline__ void run(const f32x4& a, const f32x4& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const ConvArgs p) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int VE = Elem<T>::VE;
+  constexpr int BKE = 128 / (int)sizeof(T);  // elements of K per step
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
+  const int tm = tile / p.ntiles_n, tn = tile - tm * p.ntiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int HW = p.H * p.W;
+  const int Ctot = p.C0 + p.C1;
+  const int chunks = Ctot / BKE;  // K-steps per tap
+  const int nk = p.taps * chunks;
+  const size_t Ktot = (size_t)p.taps * Ctot;
+
+  // ---- per-thread gather descriptors (K-step invariant) ----
+  int a_pix[A_IT], a_y[A_IT], a_x[A_IT], a_c[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int q = i * NT + tid;
+    const int row = q >> 3, pos = q & 7;
+    a_c[i] = (pos ^ ((row >> 1) & 7)) * VE;
+    const int m = m0 + row;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int n = mm / HW, rem = mm - n * HW;
+    a_y[i] = rem / p.W;
+    a_x[i] = rem - a_y[i] * p.W;
+    a_pix[i] = mm;
+  }
+  const char* b_ptr[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int q = i * NT + tid;
+    const int row = q >> 3, pos = q & 7;
+    const int c = (pos ^ ((row >> 1) & 7)) * VE;
+    const int co = n0 + row;
+    b_ptr[i] = (co < p.Cout) ? p.w + ((size_t)co * Ktot + c) * sizeof(T) : nullptr;
+  }
+
+  int ld_tap = 0, ld_ch = 0;  // K-step that the next issue() loads
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + A_BYTES;
+    const int cbase = ld_ch * BKE;
+    const bool second = cbase >= p.C0;
+    const char* src = second ? p.src1 : p.src0;
+    const int Cs = second ? p.C1 : p.C0;
+    const int coff = second ? cbase - p.C0 : cbase;
+    int dy = 0, dx = 0;
+    if (p.taps == 9) {
+      dy = ld_tap / 3 - 1;
+      dx = ld_tap - (dy + 1) * 3 - 1;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      const bool inb = a_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const size_t e = (size_t)(a_pix[i] + dy * p.W + dx) * Cs + coff + a_c[i];
+      const char* g = inb ? src + e * sizeof(T) : p.zero;
+      glds16(g, sA + (i * NT + wave * 64) * 16);
+    }
+    const size_t koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
+      glds16(g, sB + (i * NT + wave * 64) * 16);
+    }
+    if (++ld_ch == chunks) {
+      ld_ch = 0;
+      ++ld_tap;
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // fragment read offsets: row (lane&31) of a 32-row block, piece 2*kk + (lane>>5)
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int a_off[MI], b_off[NI], a_sw[MI], b_sw[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * WTM + mi * 32 + frow;
+    a_off[mi] = row * 128;
+    a_sw[mi] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = wn * WTN + ni * 32 + frow;
+    b_off[ni] = row * 128;
+    b_sw[ni] = (row >> 1) & 7;
+  }
+
+  issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt0();
+    __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
+    if (kt + 1 < nk) issue((kt + 1) & 1);
+    const char* sA = smem + (kt & 1) * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      vec_t a[MI], b[NI];
+      const int piece = 2 * kk + fhalf;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(a[mi], b[ni], acc[mi][ni]);
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  __syncthreads();  // all waves done with the operand stages; LDS is reused as per-wave slabs
+  constexpr int LDC = WTN + 4;  // floats per slab row (pad keeps the two half-waves on different banks)
+  float* slab = (float*)smem + wave * (32 * LDC);
+  const int Cout = p.Cout;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
+      }
+    __syncthreads();
+    const int mbase = m0 + wm * WTM + mi * 32;
+    const int nbase = n0 + wn * WTN;
+    if (p.out_mode == 0) {
+      constexpr int LPR = WTN / VE;   // lanes per slab row
+      constexpr int RPP = 64 / LPR;   // rows per pass
+      const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int row = ps * RPP + lr;
+        const int m = mbase + row, n = nbase + lc;
+        if (m < p.M && n < Cout) {
+          float v[VE];
+#pragma unroll
+          for (int e = 0; e < VE; e += 4) {
+            const f32x4 t = *(const f32x4*)(slab + row * LDC + lc + e);
+            v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+          }
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] += p.bias[n + e];
+          }
+          if (p.res_mode == 1) {
+            float rv[VE];
+            vec_to_f32<T>(*(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] += rv[e];
+          } else if (p.res_mode != 0) {
+            const int img = m / HW, rem = m - img * HW;
+            const int y = rem / p.W, x = rem - y * p.W;
+            if (p.res_mode == 2) {  // residual source is (H/2, W/2): nearest-neighbour x2
+              const int Hs = p.H >> 1, Ws = p.W >> 1;
+              const size_t pix = ((size_t)img * Hs + (y >> 1)) * Ws + (x >> 1);
+              float rv[VE];
+              vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) v[e] += rv[e];
+            } else {  // residual source is (2H, 2W): 2x2 average pool
+              const int Hs = p.H << 1, Ws = p.W << 1;
+              float s[VE];
+#pragma unroll
+              for (int e = 0; e < VE; ++e) s[e] = 0.f;
+#pragma unroll
+              for (int d = 0; d < 4; ++d) {
+                const size_t pix = ((size_t)img * Hs + 2 * y + (d >> 1)) * Ws + 2 * x + (d & 1);
+                float rv[VE];
+                vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] += rv[e];
+              }
+#pragma unroll
+              for (int e = 0; e < VE; ++e) v[e] += 0.25f * s[e];
+            }
+          }
+          *(vec_t*)(p.out + ((size_t)m * Cout + n) * sizeof(T)) = f32_to_vec<T>(v);
+        }
+      }
+    } else {  // fp32 NCHW output (small Cout): lanes run along pixels for coalescing
+      const int ncols = min(WTN, Cout - nbase);
+      for (int idx = lane; idx < 32 * ncols; idx += 64) {
+        const int row = idx & 31, col = idx >> 5;
+        const int m = mbase + row;
+        if (m < p.M) {
+          const int img = m / HW, rem = m - img * HW;
+          float v = slab[row * LDC + col];
+          if (p.bias) v += p.bias[nbase + col];
+          ((float*)p.out)[((size_t)img * Cout + nbase + col) * HW + rem] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_conv(const ConvArgs& a0, hipStream_t stream) {
+  ConvArgs a = a0;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
+  a.ntiles_n = nt;
+  a.ntiles_total = mt * nt;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return ivid_set_error("conv: hipFuncSetAttribute", e);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles_total), dim3(NT), SMEM, stream, a);
+  return ivid_check_launch("conv_igemm");
+}
+
+}  // namespace
+
+extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
+                           const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
+                           int W, int Cout, int taps, int tile_cfg, void* stream) {
+  const int esz = dtype == IVID_F32 ? 4 : 2;
+  const int bke = 128 / esz, ve = 16 / esz;
+  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv: bad dtype", hipSuccess);
+  if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  if (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke) return ivid_set_error("conv: channels must be multiples of the K-step", hipSuccess);
+  if (C1 > 0 && !src1) return ivid_set_error("conv: src1 missing", hipSuccess);
+  if (out_mode == 0 && Cout % ve) return ivid_set_error("conv: Cout must be a multiple of 16 bytes for NHWC output", hipSuccess);
+  if (res_mode < 0 || res_mode > 3 || (res_mode && !res)) return ivid_set_error("conv: bad residual", hipSuccess);
+  if (res_mode == 2 && ((H | W) & 1)) return ivid_set_error("conv: up-residual needs even H,W", hipSuccess);
+  if ((long long)N * H * W >= (1ll << 31)) return ivid_set_error("conv: M too large", hipSuccess);
+  ConvArgs a;
+  a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.w = (const char*)weight; a.bias = bias;
+  a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page();
+  if (!a.zero) return -1;
+  a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
+  a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (tile_cfg == 0) {  // auto: big tile when it still fills the chip
+    const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
+    tile_cfg = (Cout >= 256 && big >= 512) ? 2 : 1;
+  }
+  if (dtype == IVID_BF16) {
+    if (tile_cfg == 2) return launch_conv<__bf16, 256, 256, 2, 4>(a, s);
+    return launch_conv<__bf16, 128, 128, 2, 2>(a, s);
+  } else {
+    if (tile_cfg == 2) return launch_conv<float, 256, 256, 2, 4>(a, s);
+    return launch_conv<float, 128, 128, 2, 2>(a, s);
+  }
+}

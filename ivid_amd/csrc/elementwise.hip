@@ -1,0 +1,206 @@
+// Small streaming kernels around the UNet and the DDPM/DDIM update (all HBM-bound, fp32 math).
+//   - PosEncoding + label embedding gather with null-class mask   (adm.py:30-33, 545-555)
+//   - SiLU on the fp32 embedding vectors                           (adm.py:175, 360)
+//   - fp32 NCHW -> NHWC (dtype, zero-padded channels, CFG batch replication) at the model boundary
+//   - one fused DDIM step: CFG combine, x0 prediction, clamp, replace_rgb / replace_depth /
+//     convex-hull depth constraint, eps re-derivation, x_{t-1}       (ddim.py:81-102,
+//     classifier_free_guidance.py:39-42)
+//   - one fused DDPM ancestral step                                 (ddpm.py:85-101, 127-131)
+//   - InpaintCFG.make_cond_inputs                                   (inpaint_cfg.py:24-49)
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+__global__ void embed_inputs_kernel(const int64_t* __restrict__ times, const int64_t* __restrict__ classes, int Bsrc,
+                                    int null_from, const float* __restrict__ freqs, int half,
+                                    const float* __restrict__ label_emb, int emb_dim, float* __restrict__ pos,
+                                    float* __restrict__ cls) {
+  const int n = blockIdx.x, src = n % Bsrc;
+  const float t = (float)times[src];
+  for (int k = threadIdx.x; k < half; k += blockDim.x) {
+    const float a = t * freqs[k];
+    pos[(size_t)n * 2 * half + k] = cosf(a);
+    pos[(size_t)n * 2 * half + half + k] = sinf(a);
+  }
+  if (cls) {
+    long long c = -1;
+    if (classes && n < null_from) c = classes[src];
+    for (int k = threadIdx.x; k < emb_dim; k += blockDim.x)
+      cls[(size_t)n * emb_dim + k] = c >= 0 ? label_emb[(size_t)c * emb_dim + k] : 0.f;
+  }
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = x[i];
+    y[i] = v / (1.0f + expf(-v));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int Bsrc, int Cin, int HW,
+                                                           int Cpad, char* __restrict__ out) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (p >= HW) return;
+  const float* xs = x + (size_t)(n % Bsrc) * Cin * HW + p;
+  char* o = out + ((size_t)n * HW + p) * Cpad * sizeof(T);
+  for (int c0 = 0; c0 < Cpad; c0 += VE) {
+    float f[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) f[e] = (c0 + e < Cin) ? xs[(size_t)(c0 + e) * HW] : 0.f;
+    *(vec_t*)(o + c0 * sizeof(T)) = f32_to_vec<T>(f);
+  }
+}
+
+struct StepPtrs {
+  const float *x_t, *eps_c, *eps_u, *rgb, *rgb_mask, *depth, *depth_mask, *convex, *noise;
+  float *x_prev, *x0;
+};
+
+// One thread = one pixel of one sample, all 4 RGBD channels (the replace / constrain terms differ per channel).
+__global__ __launch_bounds__(256) void ddim_step_kernel(StepPtrs q, ivid_ddim_coef k, int HW) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (p >= HW) return;
+  const size_t b4 = (size_t)n * 4 * HW + p, b3 = (size_t)n * 3 * HW + p, b1 = (size_t)n * HW + p;
+  float xt[4], x0[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    xt[c] = q.x_t[b4 + (size_t)c * HW];
+    float e = q.eps_c[b4 + (size_t)c * HW];
+    if (q.eps_u) e = (1.0f + k.cfg_strength) * e - k.cfg_strength * q.eps_u[b4 + (size_t)c * HW];
+    float v = k.sqrt_recip_ac * xt[c] - k.sqrt_recipm1_ac * e;  // ddim.py:36-37
+    if (k.clip_denoised) v = fminf(fmaxf(v, -1.0f), 1.0f);
+    x0[c] = v;
+  }
+  if (k.replace_rgb_w >= 0.f) {  // ddim.py:86-89 (active only while t_prev != 0)
+    const float m = q.rgb_mask[b1], w = k.replace_rgb_w, nz = k.nonzero;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float r = q.rgb[b3 + (size_t)c * HW];
+      x0[c] = (1.0f - nz) * x0[c] + nz * ((w * r + (1.0f - w) * x0[c]) * m + x0[c] * (1.0f - m));
+    }
+  }
+  if (k.replace_depth_w >= 0.f) {  // ddim.py:90-95
+    const float m = q.depth_mask[b1], w = k.replace_depth_w;
+    x0[3] = (w * q.depth[b1] + (1.0f - w) * x0[3]) * m + x0[3] * (1.0f - m);
+    if (k.constrain_w >= 0.f) {
+      const float cw = k.constrain_w;
+      x0[3] = x0[3] * m + (cw * fmaxf(x0[3], q.convex[b1]) + (1.0f - cw) * x0[3]) * (1.0f - m);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float e2 = (k.sqrt_recip_ac * xt[c] - x0[c]) / k.sqrt_recipm1_ac;  // ddim.py:43-44
+    float v = k.sqrt_ac_prev * x0[c] + k.dir_coef * e2;                      // ddim.py:99
+    if (q.noise) v += k.nonzero * k.sigma * q.noise[b4 + (size_t)c * HW];    // ddim.py:101-102
+    q.x_prev[b4 + (size_t)c * HW] = v;
+    q.x0[b4 + (size_t)c * HW] = x0[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(StepPtrs q, ivid_ddpm_coef k, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float xt = q.x_t[i];
+  float e = q.eps_c[i];
+  if (q.eps_u) e = (1.0f + k.cfg_strength) * e - k.cfg_strength * q.eps_u[i];
+  float x0 = k.sqrt_recip_ac * xt - k.sqrt_recipm1_ac * e;  // ddpm.py:105-108
+  if (k.clip_denoised) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  float v = k.coef1 * x0 + k.coef2 * xt;  // ddpm.py:57-60
+  if (q.noise) v += k.std * q.noise[i];   // ddpm.py:130
+  q.x_prev[i] = v;
+  q.x0[i] = x0;
+}
+
+__global__ __launch_bounds__(256) void inpaint_cond_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ mask,
+                                                           const float* __restrict__ mask_rgb,
+                                                           const float* __restrict__ nrgb,
+                                                           const float* __restrict__ nd, float* __restrict__ out,
+                                                           int HW) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (p >= HW) return;
+  const int Co = mask_rgb ? 10 : 9;
+  const size_t b4 = (size_t)n * 4 * HW + p, b3 = (size_t)n * 3 * HW + p, b1 = (size_t)n * HW + p;
+  float* o = out + (size_t)n * Co * HW + p;
+  int c = 0;
+  for (int j = 0; j < 4; ++j) o[(size_t)(c++) * HW] = x[b4 + (size_t)j * HW];
+  const float m = mask[b1];
+  const float mr = mask_rgb ? mask_rgb[b1] : m;
+  if (mask_rgb) o[(size_t)(c++) * HW] = mr;
+  for (int j = 0; j < 3; ++j)
+    o[(size_t)(c++) * HW] = y[b4 + (size_t)j * HW] * mr + nrgb[b3 + (size_t)j * HW] * (1.0f - mr);
+  o[(size_t)(c++) * HW] = y[b4 + (size_t)3 * HW] * m + nd[b1] * (1.0f - m);
+  o[(size_t)(c++) * HW] = m;
+}
+
+}  // namespace
+
+extern "C" int ivid_embed_inputs(const int64_t* times, const int64_t* classes, int Bsrc, int N, int null_from,
+                                 const float* freqs, int half, const float* label_emb, int emb_dim, float* pos,
+                                 float* cls, void* stream) {
+  if (Bsrc <= 0 || N <= 0) return ivid_set_error("embed_inputs: bad batch", hipSuccess);
+  if (cls && classes && !label_emb) return ivid_set_error("embed_inputs: label_emb missing", hipSuccess);
+  hipLaunchKernelGGL(embed_inputs_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, times, classes, Bsrc, null_from,
+                     freqs, half, label_emb, emb_dim, pos, cls);
+  return ivid_check_launch("embed_inputs");
+}
+
+extern "C" int ivid_silu_f32(const float* x, float* y, long long n, void* stream) {
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  return ivid_check_launch("silu");
+}
+
+extern "C" int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Cpad,
+                                 void* out, void* stream) {
+  const int ve = dtype == IVID_F32 ? 4 : 8;
+  if (Cpad % ve || Cpad < Cin) return ivid_set_error("nchw_to_nhwc: bad Cpad", hipSuccess);
+  const int HW = H * W;
+  dim3 grid((HW + 255) / 256, N);
+  if (dtype == IVID_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, HW, Cpad,
+                       (char*)out);
+  else if (dtype == IVID_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, HW, Cpad,
+                       (char*)out);
+  else
+    return ivid_set_error("nchw_to_nhwc: bad dtype", hipSuccess);
+  return ivid_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int ivid_ddim_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddim_coef* host_coef,
+                              const float* rgb, const float* rgb_mask, const float* depth, const float* depth_mask,
+                              const float* convex, const float* noise, float* x_prev, float* x0, int B, int HW,
+                              void* stream) {
+  ivid_ddim_coef k = *host_coef;
+  if (k.replace_rgb_w >= 0.f && (!rgb || !rgb_mask)) return ivid_set_error("ddim_step: replace_rgb tensors missing", hipSuccess);
+  if (k.replace_depth_w >= 0.f && (!depth || !depth_mask)) return ivid_set_error("ddim_step: replace_depth tensors missing", hipSuccess);
+  if (k.replace_depth_w >= 0.f && k.constrain_w >= 0.f && !convex) return ivid_set_error("ddim_step: convex missing", hipSuccess);
+  if (k.sigma != 0.f && !noise) return ivid_set_error("ddim_step: noise missing for eta > 0", hipSuccess);
+  StepPtrs q{x_t, eps_c, eps_u, rgb, rgb_mask, depth, depth_mask, convex, k.sigma != 0.f ? noise : nullptr, x_prev, x0};
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, q, k, HW);
+  return ivid_check_launch("ddim_step");
+}
+
+extern "C" int ivid_ddpm_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddpm_coef* host_coef,
+                              const float* noise, float* x_prev, float* x0, int B, int HW, void* stream) {
+  ivid_ddpm_coef k = *host_coef;
+  if (k.std != 0.f && !noise) return ivid_set_error("ddpm_step: noise missing", hipSuccess);
+  StepPtrs q{x_t, eps_c, eps_u, nullptr, nullptr, nullptr, nullptr, nullptr, k.std != 0.f ? noise : nullptr, x_prev, x0};
+  const long long total = (long long)B * 4 * HW;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, k,
+                     total);
+  return ivid_check_launch("ddpm_step");
+}
+
+extern "C" int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const float* mask_rgb,
+                                 const float* noise_rgb, const float* noise_depth, float* out, int B, int HW,
+                                 void* stream) {
+  hipLaunchKernelGGL(inpaint_cond_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, y, mask,
+                     mask_rgb, noise_rgb, noise_depth, out, HW);
+  return ivid_check_launch("inpaint_cond");
+}

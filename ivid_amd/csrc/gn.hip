@@ -1,0 +1,265 @@
+// GroupNorm32 (+SiLU, +FiLM scale/shift, +nearest-up / avg-pool-down, + skip concat) for NHWC tensors.
+//
+// Reference: GroupNorm32 (adm.py:36-41: nn.GroupNorm(32, C, eps=1e-5, affine) evaluated in fp32),
+// SiLU (adm.py:159,180,485), FiLM `out_norm(h)*(1+scale)+shift` (adm.py:214-218), the resampling
+// between activation and conv in up/down ResBlocks (adm.py:203-208) and torch.cat([h, hs.pop()])
+// (adm.py:563), which is never materialised on its own: the three kernels read two base pointers.
+//
+// All three are HBM-bound streaming kernels (16-byte pieces, consecutive lanes = consecutive
+// channel pieces of one pixel = fully coalesced NHWC rows):
+//   gn_partial  : per (n, pixel-chunk) block -> per-channel sum / sum of squares (fp32)
+//   gn_finalize : per (n, group) block -> mean/rstd in fp64 from the partials, folded with gamma/beta
+//                 and the FiLM scale/shift into one (a,b) pair per (n, channel)
+//   gn_apply    : out = act(x*a + b), with resampling, written once as the conv's input tensor
+// Group statistics that straddle the concat seam (e.g. 1792 = 1024+768 channels, 56-channel groups)
+// need no special casing because partials are per channel.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int GN_NT = 256;
+
+__host__ __device__ inline int gn_ppc(int HW) { return HW >= 4096 ? 256 : 64; }
+
+template <typename T>
+__global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restrict__ src0, int C0,
+                                                           const char* __restrict__ src1, int C1, int HW, int ppc,
+                                                           int nchunks, float* __restrict__ partial) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  __shared__ float red[GN_NT * VE * 2];
+  const int C = C0 + C1, CV = C / VE, CV0 = C0 / VE;
+  const int chunk = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int CVs = CV < GN_NT ? CV : GN_NT;
+  const int PIF = CV < GN_NT ? GN_NT / CV : 1;  // pixels in flight per block iteration
+  const int p0 = t / CVs;
+  const int pbeg = chunk * ppc, pend = min(pbeg + ppc, HW);
+  float* outp = partial + ((size_t)n * nchunks + chunk) * C * 2;
+  for (int cv = t - p0 * CVs; cv < CV; cv += CVs) {
+    float s[VE], ss[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[e] = ss[e] = 0.f;
+    if (p0 < PIF) {
+      const bool second = cv >= CV0;
+      const char* base = second ? src1 : src0;
+      const int Cs = second ? C1 : C0;
+      const int cc = (second ? cv - CV0 : cv) * VE;
+      for (int p = pbeg + p0; p < pend; p += PIF) {
+        const vec_t v = *(const vec_t*)(base + (((size_t)n * HW + p) * Cs + cc) * sizeof(T));
+        float f[VE];
+        vec_to_f32<T>(v, f);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          s[e] += f[e];
+          ss[e] += f[e] * f[e];
+        }
+      }
+    }
+    if (PIF == 1) {
+      if (p0 == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          outp[(cv * VE + e) * 2] = s[e];
+          outp[(cv * VE + e) * 2 + 1] = ss[e];
+        }
+      }
+    } else {
+      // reduce over the PIF threads that share this channel piece (loop body runs once here: CV <= NT)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        red[(t * VE + e) * 2] = s[e];
+        red[(t * VE + e) * 2 + 1] = ss[e];
+      }
+      __syncthreads();
+      if (p0 == 0) {
+        for (int j = 1; j < PIF; ++j) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            s[e] += red[((t + j * CVs) * VE + e) * 2];
+            ss[e] += red[((t + j * CVs) * VE + e) * 2 + 1];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          outp[(cv * VE + e) * 2] = s[e];
+          outp[(cv * VE + e) * 2 + 1] = ss[e];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                         int HW, int groups, float eps,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ film, int film_stride,
+                                                         int film_off, float* __restrict__ ab) {
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int cpg = C / groups;
+  const float* pp = partial + (size_t)n * nchunks * C * 2;
+  double s = 0.0, ss = 0.0;
+  for (int idx = t; idx < nchunks * cpg; idx += 64) {
+    const int ch = idx / cpg, c = g * cpg + (idx - ch * cpg);
+    s += (double)pp[((size_t)ch * C + c) * 2];
+    ss += (double)pp[((size_t)ch * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    ss += __shfl_xor(ss, off);
+  }
+  const double cnt = (double)cpg * (double)HW;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  for (int j = t; j < cpg; j += 64) {
+    const int c = g * cpg + j;
+    float a = rstd * gamma[c];
+    float b = beta[c] - meanf * a;
+    if (film) {
+      const float sc = 1.0f + film[(size_t)n * film_stride + film_off + c];
+      const float sh = film[(size_t)n * film_stride + film_off + C + c];
+      a *= sc;
+      b = b * sc + sh;
+    }
+    ab[((size_t)n * C + c) * 2] = a;
+    ab[((size_t)n * C + c) * 2 + 1] = b;
+  }
+}
+
+// resample: 0 same, 1 nearest x2 up (output 2H x 2W), 2 avg-pool x2 of activated values (output H/2 x W/2)
+template <typename T, int ACT>
+__global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict__ src0, int C0,
+                                                         const char* __restrict__ src1, int C1,
+                                                         const float* __restrict__ ab, char* __restrict__ out, int H,
+                                                         int W, int resample, int ppc) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  const int C = C0 + C1, CV = C / VE, CV0 = C0 / VE;
+  const int Ho = resample == 1 ? H * 2 : (resample == 2 ? H / 2 : H);
+  const int Wo = resample == 1 ? W * 2 : (resample == 2 ? W / 2 : W);
+  const int HWo = Ho * Wo;
+  const int chunk = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int CVs = CV < GN_NT ? CV : GN_NT;
+  const int PIF = CV < GN_NT ? GN_NT / CV : 1;
+  const int p0 = t / CVs;
+  if (p0 >= PIF) return;
+  const int pbeg = chunk * ppc, pend = min(pbeg + ppc, HWo);
+  for (int cv = t - p0 * CVs; cv < CV; cv += CVs) {
+    float a[VE], b[VE];
+    {
+      const float* abp = ab + ((size_t)n * C + (size_t)cv * VE) * 2;
+#pragma unroll
+      for (int e = 0; e < VE; e += 2) {
+        const f32x4 q = *(const f32x4*)(abp + e * 2);
+        a[e] = q[0]; b[e] = q[1]; a[e + 1] = q[2]; b[e + 1] = q[3];
+      }
+    }
+    const bool second = cv >= CV0;
+    const char* base = second ? src1 : src0;
+    const int Cs = second ? C1 : C0;
+    const int cc = (second ? cv - CV0 : cv) * VE;
+    for (int p = pbeg + p0; p < pend; p += PIF) {
+      float r[VE];
+      if (resample == 2) {
+        const int yo = p / Wo, xo = p - yo * Wo;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) r[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const size_t sp = ((size_t)n * H + 2 * yo + (d >> 1)) * W + 2 * xo + (d & 1);
+          float f[VE];
+          vec_to_f32<T>(*(const vec_t*)(base + (sp * Cs + cc) * sizeof(T)), f);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            const float y = f[e] * a[e] + b[e];
+            r[e] += ACT ? silu_f(y) : y;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) r[e] *= 0.25f;
+      } else {
+        size_t sp;
+        if (resample == 1) {
+          const int yo = p / Wo, xo = p - yo * Wo;
+          sp = ((size_t)n * H + (yo >> 1)) * W + (xo >> 1);
+        } else {
+          sp = (size_t)n * HWo + p;
+        }
+        float f[VE];
+        vec_to_f32<T>(*(const vec_t*)(base + (sp * Cs + cc) * sizeof(T)), f);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float y = f[e] * a[e] + b[e];
+          r[e] = ACT ? silu_f(y) : y;
+        }
+      }
+      *(vec_t*)(out + (((size_t)n * HWo + p) * C + (size_t)cv * VE) * sizeof(T)) = f32_to_vec<T>(r);
+    }
+  }
+}
+
+int check_channels(int dtype, int C0, int C1, const void* src1) {
+  const int ve = dtype == IVID_F32 ? 4 : 8;
+  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("gn: bad dtype", hipSuccess);
+  if (C0 <= 0 || C0 % ve || C1 < 0 || C1 % ve) return ivid_set_error("gn: channels must be multiples of 16 bytes", hipSuccess);
+  if (C1 > 0 && !src1) return ivid_set_error("gn: src1 missing", hipSuccess);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ivid_gn_num_chunks(int HW) {
+  const int ppc = gn_ppc(HW);
+  return (HW + ppc - 1) / ppc;
+}
+
+extern "C" int ivid_gn_partial(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int HW,
+                               float* partial, void* stream) {
+  if (int e = check_channels(dtype, C0, C1, src1)) return e;
+  const int ppc = gn_ppc(HW), nchunks = (HW + ppc - 1) / ppc;
+  dim3 grid(nchunks, N);
+  if (dtype == IVID_F32)
+    hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
+                       (const char*)src1, C1, HW, ppc, nchunks, partial);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
+                       (const char*)src1, C1, HW, ppc, nchunks, partial);
+  return ivid_check_launch("gn_partial");
+}
+
+extern "C" int ivid_gn_finalize(const float* partial, int nchunks, int N, int C, int HW, int groups, float eps,
+                                const float* gamma, const float* beta, const float* film, int film_stride,
+                                int film_off, float* ab, void* stream) {
+  if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize: C must be divisible by groups", hipSuccess);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial, nchunks, C, HW,
+                     groups, eps, gamma, beta, film, film_stride, film_off, ab);
+  return ivid_check_launch("gn_finalize");
+}
+
+extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, void* out,
+                             int N, int H, int W, int resample, int act, void* stream) {
+  if (int e = check_channels(dtype, C0, C1, src1)) return e;
+  if (resample < 0 || resample > 2) return ivid_set_error("gn_apply: bad resample", hipSuccess);
+  if (resample == 2 && ((H | W) & 1)) return ivid_set_error("gn_apply: avg-pool needs even H,W", hipSuccess);
+  const int Ho = resample == 1 ? H * 2 : (resample == 2 ? H / 2 : H);
+  const int Wo = resample == 1 ? W * 2 : (resample == 2 ? W / 2 : W);
+  const int HWo = Ho * Wo;
+  const int ppc = gn_ppc(HWo), nchunks = (HWo + ppc - 1) / ppc;
+  dim3 grid(nchunks, N);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, A)                                                                                              \
+  hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
+                     C1, ab, (char*)out, H, W, resample, ppc)
+  if (dtype == IVID_F32) {
+    if (act) LAUNCH(float, 1); else LAUNCH(float, 0);
+  } else {
+    if (act) LAUNCH(__bf16, 1); else LAUNCH(__bf16, 0);
+  }
+#undef LAUNCH
+  return ivid_check_launch("gn_apply");
+}

@@ -1,0 +1,8 @@
+// Host-side helpers shared by the translation units of libivid_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ivid_hip.h"
+
+int ivid_set_error(const char* what, hipError_t e);  // records message, returns nonzero
+int ivid_check_launch(const char* what);             // hipGetLastError() after a launch
+const void* ivid_zero_page();                        // 256 zero bytes in device memory (per device)

@@ -1,0 +1,190 @@
+"""AdmUnet2d — drop-in for diffusion.backbones.AdmUnet2d of the reference
+(/root/reference/diffusion/backbones/adm.py:289-566), executing on MI355X through libivid_hip.so.
+
+Same constructor kwargs (every key of configs/*.json:backbone.args, including the ignored
+`num_heads: null`), same `forward(x, times, classes=None)` signature (frameworks introspect it,
+gaussian_diffusion.py:31), same attributes (`image_size`, `out_channels`, `num_classes`, `device`,
+`dtype`), same state_dict keys and shapes, so `backbone.load_state_dict(torch.load(ckpt))` works
+with strict=True on reference checkpoints.
+
+The module holds fp32 master parameters only as a checkpoint container; compute happens in the
+HIP launch plan (plan.py) on weights repacked once per precision:
+    precision "fp32": exact-fp32 MFMA (parity mode, bit-comparable to an fmaf chain)
+    precision "bf16": bf16 MFMA with fp32 accumulate, fp32 GroupNorm/softmax/embeddings (perf mode)
+`use_fp16=True` configs (the reference's fp16 torso) select "bf16"; override with the extra kwarg
+`precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
+without a GPU / without the built library raises.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from .plan import PackedWeights, UNetPlan
+from .spec import build_spec
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: bool):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if is_buffer:
+        m.register_buffer(parts[-1], tensor)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class AdmUnet2d(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, num_classes=None, has_null_class=False,
+                 use_fp16=False, num_groups=32, num_heads=1, num_head_channels=-1, use_scale_shift_norm=True,
+                 resblock_updown=True, precision=None):
+        super().__init__()
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.has_null_class = has_null_class if num_classes is not None else False
+        self.dtype = torch.float16 if use_fp16 else torch.float32  # attribute kept for API parity (adm.py:333)
+        self.num_groups = num_groups
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.spec = build_spec(image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                               attention_resolutions, dropout, channel_mult, conv_resample, num_classes,
+                               has_null_class, use_fp16, num_groups, num_heads, num_head_channels,
+                               use_scale_shift_norm, resblock_updown)
+        precision = os.environ.get("IVID_PRECISION", precision)
+        if precision is None:
+            precision = "bf16" if use_fp16 else "fp32"
+        self.set_precision(precision)
+        self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
+        self.tile_cfg = int(os.environ.get("IVID_TILE_CFG", "0"))
+
+        # ---- parameters: same names / shapes / init statistics as the reference ----
+        self._fan_in = {}
+        for name, shape, is_buf in self.spec.schema:
+            _attach(self, name, self._init_tensor(name, shape), is_buf)
+        self._packed = None
+        self._plans = {}
+
+    # -- init mirrors torch defaults (kaiming-uniform convs/linears, N(0,1) embedding, GN 1/0) and the
+    #    reference's zero_module()'d out-convs / proj_out / final conv (adm.py:182,278,486)
+    def _init_tensor(self, name, shape):
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "freqs":
+            half = shape[0]
+            return torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)  # adm.py:28
+        zeroed = (".out_layers.3." in name) or (".proj_out." in name) or name.startswith("out.2.")
+        if zeroed:
+            return torch.zeros(shape)
+        if len(shape) == 1:
+            is_norm = any(s in name for s in (".in_layers.0.", ".out_layers.0.", ".norm.", "out.0."))
+            if is_norm:
+                return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+            bound = 1.0 / self._fan_in.get(name.rsplit(".", 1)[0], 1) ** 0.5
+            return torch.empty(shape).uniform_(-bound, bound)
+        if name == "label_emb.weight":
+            return torch.randn(shape)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        self._fan_in[name.rsplit(".", 1)[0]] = fan_in
+        bound = 1.0 / fan_in ** 0.5  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+        return torch.empty(shape).uniform_(-bound, bound)
+
+    # ---- precision / packing ----
+    def set_precision(self, precision):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
+        self._packed = None
+        self._plans = {}
+
+    def convert_to_fp16(self):
+        """Reference API (adm.py:508-514): low-precision torso -> bf16 MFMA perf mode here."""
+        self.set_precision("bf16")
+
+    def convert_to_fp32(self):
+        self.set_precision("fp32")
+
+    def _invalidate(self):
+        self._packed = None
+        self._plans = {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return out
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def example_inputs(self):
+        return {
+            "x": torch.randn(1, self.in_channels, self.image_size, self.image_size).to(self.device),
+            "times": torch.zeros((1,), dtype=torch.long).to(self.device),
+            "classes": torch.randint(0, self.num_classes, (1,)).to(self.device) if self.num_classes is not None else None,
+        }
+
+    def _weights(self):
+        if self._packed is None:
+            dev = self.device
+            if dev.type != "cuda":
+                raise _lib.IvidHipError(
+                    "AdmUnet2d runs only on an MI355X (HIP) device: move it with .cuda() first; "
+                    "ivid_amd has no CPU execution path")
+            _lib.load()
+            dt = _lib.F32 if self.precision == "fp32" else _lib.BF16
+            self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt)
+        return self._packed
+
+    def plan(self, batch, stacked=False):
+        key = (batch, stacked)
+        if key not in self._plans:
+            self._plans[key] = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
+        return self._plans[key]
+
+    # ---- reference-compatible forward ----
+    @torch.no_grad()
+    def forward(self, x, times, classes=None):
+        assert classes is None or self.num_classes is not None, "this model is not class-conditioned"
+        if classes is not None:
+            assert classes.shape == (x.shape[0],), "classes must be a 1-D batch of labels"
+            assert self.has_null_class or bool(torch.all(classes >= 0)), "this model does not have a null class"
+        assert x.shape[1:] == (self.in_channels, self.image_size, self.image_size), \
+            f"expected input [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
+        out = self.plan(x.shape[0], False).run(x.float(), times, classes, self.use_graph)
+        return out.clone()
+
+    @torch.no_grad()
+    def forward_cfg(self, x, times, classes):
+        """Both classifier-free-guidance branches in ONE stacked forward of batch 2B (rows [0,B) use
+        `classes`, rows [B,2B) the null class): returns (eps_cond, eps_uncond) views of a static buffer
+        that stay valid until the next call.  Replaces the two sequential backbone calls of
+        classifier_free_guidance.py:39-42 / inpaint_cfg.py:80-83."""
+        assert self.num_classes is not None and classes is not None
+        b = x.shape[0]
+        out = self.plan(b, True).run(x.float(), times, classes, self.use_graph)
+        return out[:b], out[b:]

@@ -1,0 +1,337 @@
+"""Launch plan of one ADM UNet forward on MI355X.
+
+A plan is built once per (batch, stacked-CFG) shape: it owns the activation arena (NHWC tensors of
+the compute dtype), the repacked weights are shared, and the forward is a precomputed list of
+C-ABI launches (include/ivid_hip.h) that is replayed as ONE hipGraph after the first eager run —
+the reference issues ~650-700 separate torch kernels per forward.
+
+Data flow of a ResBlock (adm.py:192-222), all tensors NHWC:
+    stats(x|skip) -> (a,b) -> act1 = silu(x*a+b) [+up/down resample, concat materialised]
+    h1 = conv3x3(act1)                     (bias fused)
+    stats(h1) + FiLM(scale,shift) -> (a,b) -> act2 = silu(h1*a+b)
+    out = conv3x3(act2) + bias + skip      (skip = x, resampled x, or conv1x1(x|skip))
+"""
+import ctypes as C
+
+import torch
+
+from ... import _lib
+from .spec import Attn, Res, UNetSpec
+
+_TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+
+
+def _pad_to(c, m):
+    return (c + m - 1) // m * m
+
+
+class PackedWeights:
+    """Weights repacked once into the kernels' layouts: conv [Cout][tap][Cin] in the compute dtype,
+    Linear / GroupNorm / bias / embedding tables in fp32, all emb_layers fused into one matrix."""
+
+    def __init__(self, spec: UNetSpec, sd, device, dtype):
+        self.dtype = dtype
+        tdt = _TORCH_DT[dtype]
+        self.kstep = 32 if dtype == _lib.F32 else 64
+        g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
+        t = {}
+
+        def conv3(name, pad_cin=None):
+            w = g(name + ".weight").permute(0, 2, 3, 1)  # [Cout,3,3,Cin]
+            if pad_cin is not None and pad_cin != w.shape[-1]:
+                w = torch.nn.functional.pad(w, (0, pad_cin - w.shape[-1]))
+            t[name + ".weight"] = w.reshape(w.shape[0], -1).to(tdt).contiguous()
+            t[name + ".bias"] = g(name + ".bias").contiguous()
+
+        def conv1(name):
+            w = g(name + ".weight")
+            t[name + ".weight"] = w.reshape(w.shape[0], -1).to(tdt).contiguous()
+            t[name + ".bias"] = g(name + ".bias").contiguous()
+
+        def vec(name):
+            t[name + ".weight"] = g(name + ".weight").contiguous()
+            t[name + ".bias"] = g(name + ".bias").contiguous()
+
+        self.cin_pad = _pad_to(spec.in_channels, self.kstep)
+        conv3("input_blocks.0.0", self.cin_pad)
+        emb_w, emb_b = [], []
+        for op in [o for st in spec.stages for o in st.ops]:
+            p = op.prefix
+            if isinstance(op, Res):
+                vec(p + ".in_layers.0"); conv3(p + ".in_layers.2")
+                vec(p + ".out_layers.0"); conv3(p + ".out_layers.3")
+                if op.has_skip_conv:
+                    conv1(p + ".skip_connection")
+                emb_w.append(g(p + ".emb_layers.1.weight")); emb_b.append(g(p + ".emb_layers.1.bias"))
+            else:
+                vec(p + ".norm"); conv1(p + ".qkv"); conv1(p + ".proj_out")
+        vec("out.0"); conv3("out.2")
+        # embedding path stays fp32 in both modes (the reference never casts nn.Linear, backbones/utils.py:6-13)
+        t["emb_all.weight"] = torch.cat(emb_w, 0).contiguous()
+        t["emb_all.bias"] = torch.cat(emb_b, 0).contiguous()
+        for n in ("time_embed.1", "time_embed.3"):
+            vec(n)
+        t["freqs"] = g("time_embed.0.freqs").contiguous()
+        if spec.num_classes is not None:
+            t["label_emb"] = g("label_emb.weight").contiguous()
+        self.t = t
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+class _Arena:
+    """Stream-ordered buffer pool: a buffer may be handed out again as soon as its last consumer
+    launch has been *enqueued* (single stream, in-order)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = []
+        self.all = []
+
+    def get(self, nbytes):
+        nbytes = max(256, (nbytes + 255) // 256 * 256)
+        best = None
+        for i, b in enumerate(self.free):
+            if b.numel() >= nbytes and (best is None or b.numel() < self.free[best].numel()):
+                best = i
+        if best is not None and self.free[best].numel() <= 2 * nbytes:
+            return self.free.pop(best)
+        b = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.all.append(b)
+        return b
+
+    def put(self, b):
+        self.free.append(b)
+
+    def total_bytes(self):
+        return sum(b.numel() for b in self.all)
+
+
+class _Act:
+    """An NHWC activation living in an arena buffer."""
+    __slots__ = ("buf", "n", "side", "c")
+
+    def __init__(self, buf, n, side, c):
+        self.buf, self.n, self.side, self.c = buf, n, side, c
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+class UNetPlan:
+    def __init__(self, spec: UNetSpec, weights: PackedWeights, device, bsrc, stacked, tile_cfg=0):
+        self.spec, self.w, self.device = spec, weights, device
+        self.dtype = weights.dtype
+        self.esz = 4 if self.dtype == _lib.F32 else 2
+        self.bsrc = bsrc
+        self.n = 2 * bsrc if stacked else bsrc
+        self.null_from = bsrc if stacked else self.n
+        self.tile_cfg = tile_cfg
+        self.lib = _lib.load()
+        self.arena = _Arena(device)
+        self.launches = []      # (cfunc, args)
+        self.graph = None
+        self.warm = False
+        S = spec.image_size
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x_in = torch.zeros(bsrc, spec.in_channels, S, S, **f32)
+        self.t_in = torch.zeros(bsrc, dtype=torch.int64, device=device)
+        self.c_in = torch.full((bsrc,), -1, dtype=torch.int64, device=device)
+        self.out = torch.zeros(self.n, spec.out_channels, S, S, **f32)
+        self._keep = []         # small fp32 tensors referenced by raw pointer
+        # hipGraph capture is illegal on the legacy default stream, which is torch's current stream
+        # unless the caller changed it: the plan runs on its own stream, fenced against the caller's.
+        self.stream = torch.cuda.Stream(device=device)
+        self._build()
+
+    # ---- launch recording ----
+    def _rec(self, name, *args):
+        self.launches.append((getattr(self.lib, name), name, args))
+
+    def _f32(self, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _new(self, n, side, c):
+        return _Act(self.arena.get(n * side * side * c * self.esz), n, side, c)
+
+    def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps):
+        self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
+                  self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
+                  self.tile_cfg)
+
+    def _linear(self, x, k, wname, out, cout, res=None):
+        self._conv(_lib.F32, x.data_ptr(), k, None, 0, wname, out.data_ptr(), res.data_ptr() if res is not None else None,
+                   1 if res is not None else 0, 0, self.n, 1, 1, cout, 1)
+
+    def _gn(self, x0: _Act, x1, gname, film_off, resample, act):
+        """GroupNorm(+FiLM)(+SiLU)(+resample) of cat(x0,x1) -> new activation."""
+        n, side = x0.n, x0.side
+        c0, c1 = x0.c, (x1.c if x1 is not None else 0)
+        c = c0 + c1
+        hw = side * side
+        nch = self.lib.ivid_gn_num_chunks(hw)
+        partial = self.arena.get(n * nch * c * 2 * 4)
+        ab = self.arena.get(n * c * 2 * 4)
+        p1 = x1.ptr if x1 is not None else None
+        self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, p1, c1, n, hw, partial.data_ptr())
+        film = self.embproj.data_ptr() if film_off is not None else None
+        self._rec("ivid_gn_finalize", partial.data_ptr(), nch, n, c, hw, self.spec.num_groups, 1e-5,
+                  self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr(), film,
+                  self.spec.emb_total, film_off if film_off is not None else 0, ab.data_ptr())
+        so = {0: side, 1: side * 2, 2: side // 2}[resample]
+        y = self._new(n, so, c)
+        self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, p1, c1, ab.data_ptr(), y.ptr, n, side, side, resample, act)
+        self.arena.put(partial)
+        self.arena.put(ab)
+        return y
+
+    # ---- ops ----
+    def _res(self, op: Res, x: _Act, skip):
+        n = x.n
+        resample = {"same": 0, "up": 1, "down": 2}[op.mode]
+        act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
+        so = op.res_out
+        h1 = self._new(n, so, op.cout)
+        self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
+                   op.cout, 9)
+        self.arena.put(act1.buf)
+        act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
+        self.arena.put(h1.buf)
+        out = self._new(n, so, op.cout)
+        if op.has_skip_conv:
+            assert op.mode == "same"
+            r = self._new(n, so, op.cout)
+            self._conv(self.dtype, x.ptr, x.c, skip.ptr if skip is not None else None, skip.c if skip is not None else 0,
+                       op.prefix + ".skip_connection", r.ptr, None, 0, 0, n, so, so, op.cout, 1)
+            res_ptr, res_mode = r.ptr, 1
+        else:
+            assert skip is None
+            r = None
+            res_ptr, res_mode = x.ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
+        self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
+                   n, so, so, op.cout, 9)
+        self.arena.put(act2.buf)
+        if r is not None:
+            self.arena.put(r.buf)
+        return out
+
+    def _attn(self, op: Attn, x: _Act):
+        n, side, c = x.n, x.side, x.c
+        xn = self._gn(x, None, op.prefix + ".norm", None, 0, 0)
+        qkv = self._new(n, side, 3 * c)
+        self._conv(self.dtype, xn.ptr, c, None, 0, op.prefix + ".qkv", qkv.ptr, None, 0, 0, n, side, side, 3 * c, 1)
+        self.arena.put(xn.buf)
+        a = self._new(n, side, c)
+        self._rec("ivid_attention", self.dtype, qkv.ptr, a.ptr, n, side * side, op.heads)
+        self.arena.put(qkv.buf)
+        out = self._new(n, side, c)
+        self._conv(self.dtype, a.ptr, c, None, 0, op.prefix + ".proj_out", out.ptr, x.ptr, 1, 0, n, side, side, c, 1)
+        self.arena.put(a.buf)
+        return out
+
+    def _build(self):
+        sp, w, n = self.spec, self.w, self.n
+        mc, ed = sp.model_channels, sp.emb_dim
+        # ---- embeddings (adm.py:545-555 + every ResBlock's emb_layers, adm.py:176), fp32 ----
+        pos = self._f32(n, mc)
+        cls = self._f32(n, ed) if sp.num_classes is not None else None
+        self._rec("ivid_embed_inputs", self.t_in.data_ptr(), self.c_in.data_ptr() if cls is not None else None,
+                  self.bsrc, n, self.null_from, w["freqs"].data_ptr(), mc // 2,
+                  w["label_emb"].data_ptr() if cls is not None else None, ed, pos.data_ptr(),
+                  cls.data_ptr() if cls is not None else None)
+        e1, s1, emb, semb = self._f32(n, ed), self._f32(n, ed), self._f32(n, ed), self._f32(n, ed)
+        self.embproj = self._f32(n, sp.emb_total)
+        self._linear(pos, mc, "time_embed.1", e1, ed)
+        self._rec("ivid_silu_f32", e1.data_ptr(), s1.data_ptr(), n * ed)
+        self._linear(s1, ed, "time_embed.3", emb, ed, res=cls)
+        self._rec("ivid_silu_f32", emb.data_ptr(), semb.data_ptr(), n * ed)
+        self._linear(semb, ed, "emb_all", self.embproj, sp.emb_total)
+        # ---- stem ----
+        S = sp.image_size
+        xin = self._new(n, S, w.cin_pad)
+        self._rec("ivid_nchw_to_nhwc", self.dtype, self.x_in.data_ptr(), self.bsrc, n, sp.in_channels, S, S, w.cin_pad,
+                  xin.ptr)
+        h = self._new(n, S, sp.stem_out)
+        self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9)
+        self.arena.put(xin.buf)
+        stash = [h]
+        # ---- encoder / bottleneck / decoder ----
+        for st in sp.stages:
+            if st.conv_in:
+                continue
+            skip = stash.pop() if st.kind == "out" else None
+            first = True
+            for op in st.ops:
+                prev = h
+                if isinstance(op, Res):
+                    h = self._res(op, prev, skip if first else None)
+                else:
+                    h = self._attn(op, prev)
+                # the stage input may still be referenced by the skip stash; intermediates are not
+                if not any(prev is s for s in stash):
+                    self.arena.put(prev.buf)
+                if first and skip is not None:
+                    self.arena.put(skip.buf)
+                first = False
+            if st.kind == "in":
+                stash.append(h)
+        assert not stash
+        # ---- head: GN + SiLU + conv3x3 -> fp32 NCHW (adm.py:565-566) ----
+        act = self._gn(h, None, "out.0", None, 0, 1)
+        self.arena.put(h.buf)
+        self._conv(self.dtype, act.ptr, sp.final_c, None, 0, "out.2", self.out.data_ptr(), None, 0, 1, n, S, S,
+                   sp.out_channels, 9)
+        self.arena.put(act.buf)
+
+    # ---- execution ----
+    def _enqueue(self, stream):
+        sp = C.c_void_p(stream)
+        for fn, name, args in self.launches:
+            st = fn(*args, sp)
+            if st != 0:
+                _lib.check(st, name)
+
+    def run(self, x, times, classes, use_graph=True):
+        """x [bsrc,Cin,S,S] fp32, times [bsrc] int64, classes [bsrc] int64 or None -> self.out (static buffer)."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x)
+            self.t_in.copy_(times)
+            if self.spec.num_classes is not None:
+                if classes is None:
+                    self.c_in.fill_(-1)
+                else:
+                    self.c_in.copy_(classes)
+            self.launch(use_graph)
+        cur.wait_stream(self.stream)
+        return self.out
+
+    def launch(self, use_graph=True):
+        """Enqueue one forward on self.stream from the static input buffers (no host sync)."""
+        stream = self.stream.cuda_stream
+        if not use_graph or not self.warm:
+            self._enqueue(stream)   # first run is eager: sets kernel attributes, creates the zero page
+            self.warm = True
+            return
+        if self.graph is None:
+            _lib.call("ivid_graph_begin", C.c_void_p(stream))
+            try:
+                self._enqueue(stream)
+            finally:
+                gh = C.c_void_p()
+                st = self.lib.ivid_graph_end(C.c_void_p(stream), C.byref(gh))
+            _lib.check(st, "ivid_graph_end")
+            self.graph = gh
+        _lib.call("ivid_graph_launch", self.graph, C.c_void_p(stream))
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.ivid_graph_destroy(self.graph)
+        except Exception:
+            pass

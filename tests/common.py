@@ -1,0 +1,62 @@
+"""Shared test scaffolding: the mini model configs, seeded inputs, synthetic checkpoints, error metrics."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+from oracle.synth import synth_state_dict  # noqa: E402
+
+# A 3-level, 32x32 ADM UNet that exercises every code path of the big ones in < 1 s on CPU:
+# attention at T=256 and T=64, skip-conv ResBlocks (64->128), down/up ResBlocks, skip concat whose
+# GroupNorm groups straddle the seam (192 = 128+64 channels -> 6-channel groups), class embedding
+# with null class.
+MINI = dict(image_size=32, in_channels=4, out_channels=4, model_channels=64, num_res_blocks=2,
+            num_classes=10, has_null_class=True, channel_mult=[1, 2, 2], attention_resolutions=[16, 8],
+            num_groups=32, num_heads=None, num_head_channels=64, dropout=0.0, use_fp16=False)
+MINI_COND = dict(MINI, in_channels=10)
+MINI_UNCLASS = dict(MINI, num_classes=None, has_null_class=False)
+
+# backbone.args of the reference configs (configs/*.json) with use_fp16 forced False for fp32 parity
+SMALL128 = dict(image_size=128, in_channels=4, out_channels=4, model_channels=128, num_res_blocks=2,
+                num_classes=None, has_null_class=False, channel_mult=[1, 1, 2, 3, 4],
+                attention_resolutions=[32, 16, 8], num_groups=32, num_heads=None, num_head_channels=64,
+                dropout=0.0, use_fp16=False)
+LARGE128 = dict(image_size=128, in_channels=4, out_channels=4, model_channels=256, num_res_blocks=2,
+                num_classes=1000, has_null_class=True, channel_mult=[1, 1, 2, 3, 4],
+                attention_resolutions=[32, 16, 8], num_groups=32, num_heads=None, num_head_channels=64,
+                dropout=0.0, use_fp16=False)
+
+
+def schema_for(args):
+    from ivid_amd.diffusion.backbones.spec import build_spec
+    return [(n, s) for n, s, _ in build_spec(**args).schema]
+
+
+def synth_weights(args, seed=0):
+    return synth_state_dict(schema_for(args), seed)
+
+
+def seeded_randn(seed, *shape):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def max_rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))

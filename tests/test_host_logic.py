@@ -1,0 +1,147 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls — there is no GPU here)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import common as C
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ivid_amd import _lib
+    hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
+    declared = set(re.findall(r"\b(ivid_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ivid_ddim_coef", "ivid_ddpm_coef"}
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ivid_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.ivid_version() >= 1
+
+
+def test_ctypes_structs_match_header_layout():
+    from ivid_amd import _lib
+    assert ctypes.sizeof(_lib.DdimCoef) == 11 * 4
+    assert ctypes.sizeof(_lib.DdpmCoef) == 7 * 4
+
+
+def test_product_has_no_cpu_fallback():
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    from ivid_amd._lib import IvidHipError
+    m = AdmUnet2d(**C.MINI)
+    with pytest.raises(IvidHipError):
+        m(torch.zeros(1, 4, 32, 32), torch.zeros(1, dtype=torch.long), None)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(C.ROOT, "ivid_amd")):
+        for f in fs:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), re.M):
+                bad.append(f)
+    assert not bad, f"product files import the oracle: {bad}"
+
+
+@pytest.mark.parametrize("args", [C.MINI, C.MINI_COND, C.MINI_UNCLASS, C.SMALL128, C.LARGE128])
+def test_state_dict_schema_and_strict_load(args):
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    m = AdmUnet2d(**args)
+    sd = C.synth_weights(args, 0)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.state_dict()["out.2.weight"], sd["out.2.weight"])
+    # fresh model reproduces the reference's zero-init semantics (adm.py:182,278,486)
+    fresh = AdmUnet2d(**args).state_dict()
+    assert float(fresh["out.2.weight"].abs().max()) == 0.0
+    assert float(fresh["middle_block.1.proj_out.weight"].abs().max()) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference not mounted")
+def test_reference_config_json_loads_unchanged_and_schema_matches_reference():
+    import sys
+    sys.path.insert(0, "/root/reference")
+    from diffusion.backbones import AdmUnet2d as Ref
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    for fn in sorted(os.listdir("/root/reference/configs")):
+        cfg = json.load(open(os.path.join("/root/reference/configs", fn)))
+        mine, ref = AdmUnet2d(**cfg["backbone"]["args"]), Ref(**cfg["backbone"]["args"])
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys()), fn
+        assert all(a[k].shape == b[k].shape for k in a), fn
+        assert torch.equal(a["time_embed.0.freqs"], b["time_embed.0.freqs"])
+    sys.path.remove("/root/reference")
+    for k in [k for k in sys.modules if k == "diffusion" or k.startswith("diffusion.")]:
+        del sys.modules[k]
+
+
+def test_spec_topology_large():
+    from ivid_amd.diffusion.backbones.spec import Attn, Res, build_spec
+    sp = build_spec(**C.LARGE128)
+    ops = [o for st in sp.stages for o in st.ops]
+    assert sum(isinstance(o, Res) for o in ops) == 35 and sum(isinstance(o, Attn) for o in ops) == 16
+    assert sp.emb_total == sum(2 * o.cout for o in ops if isinstance(o, Res))
+    ups = [o for o in ops if isinstance(o, Res) and o.mode == "up"]
+    downs = [o for o in ops if isinstance(o, Res) and o.mode == "down"]
+    assert len(ups) == 4 and len(downs) == 4
+    assert [o.prefix for o in ups] == ["output_blocks.2.2", "output_blocks.5.2", "output_blocks.8.2", "output_blocks.11.1"]
+    assert max(o.cin for o in ops if isinstance(o, Res)) == 2048
+    assert {(o.c, o.heads, o.res ** 2) for o in ops if isinstance(o, Attn)} == {(512, 8, 1024), (768, 12, 256), (1024, 16, 64)}
+
+
+def test_framework_tables_and_sampler_coefficients_match_oracle_formulas():
+    from ivid_amd.diffusion import frameworks, samplers
+    from oracle import sampler_oracle
+
+    class Dummy:
+        image_size, out_channels = 32, 4
+        def forward(self, x, times, classes=None):
+            return x
+    fw = frameworks.ClassifierFreeGuidance(Dummy(), timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    assert np.array_equal(fw.betas, sampler_oracle.linear_betas(1000)) and fw.betas.dtype == np.float64
+    assert set(fw.backbone_args.keys()) == {"x", "times", "classes"}
+    s = samplers.DdimSampler(fw)
+    ac = np.cumprod(1 - fw.betas)
+    k = s._coef(1000, 980, 0.5, 0.5, False, -1, -1, -1)
+    ab, abp = np.float32(ac[999]), np.float32(ac[979])
+    sigma = np.float32(0.5) * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
+    assert k.sigma == pytest.approx(float(sigma), rel=1e-6)
+    assert k.sqrt_recip_ac == np.float32(np.sqrt(1 / ac[999]))
+    assert k.nonzero == 1.0 and s._coef(20, 0, 0.0, 0.0, False, -1, -1, -1).nonzero == 0.0
+    assert s._coef(20, 0, 0.7, 0.0, False, -1, -1, -1).sigma == 0.0  # alpha_bar_prev[0] = 1
+    d = samplers.DdpmSampler(fw)
+    assert d._coef(0, 0.0, False).std == 0.0
+    assert d.posterior_log_variance_clipped[0] == d.posterior_log_variance_clipped[1]
+    cos = frameworks.GaussianDiffusion(Dummy(), timesteps=50, beta_schedule="cosine")
+    assert cos.betas.shape == (50,) and cos.betas.max() <= 0.999
+
+
+def test_sampler_signatures_match_reference_positional_order():
+    import inspect
+    from ivid_amd.diffusion import samplers
+    assert list(inspect.signature(samplers.DdimSampler.sample).parameters)[:9] == [
+        "self", "num", "image_size", "noise", "classes", "steps", "clip_denoised", "eta", "verbose"]
+    assert list(inspect.signature(samplers.DdpmSampler.sample).parameters)[:8] == [
+        "self", "num", "steps", "image_size", "noise", "classes", "clip_denoised", "verbose"]
+    assert list(inspect.signature(samplers.DdimSampler.sample_once).parameters)[:10] == [
+        "self", "x_t", "t", "t_prev", "classes", "clip_denoised", "eta", "replace_rgb", "replace_depth", "constrain_depth"]
+
+
+def test_install_aliases_reference_package_names():
+    import sys
+    import ivid_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "diffusion" or k.startswith("diffusion.") or k == "rgbd_3d"}
+    try:
+        ivid_amd.install()
+        import diffusion.backbones as b
+        import diffusion.samplers as s
+        assert b.AdmUnet2d.__module__.startswith("ivid_amd.") and s.DdimSampler.__module__.startswith("ivid_amd.")
+    finally:
+        for k in [k for k in sys.modules if k == "diffusion" or k.startswith("diffusion.") or k == "rgbd_3d"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
