@@ -121,8 +121,10 @@ class _Act:
 
 
 class UNetPlan:
-    def __init__(self, spec: UNetSpec, weights: PackedWeights, device, bsrc, stacked, tile_cfg=0):
+    def __init__(self, spec: UNetSpec, weights: PackedWeights, device, bsrc, stacked, tile_cfg=0, debug=False):
         self.spec, self.w, self.device = spec, weights, device
+        self.debug = debug      # eager-only: snapshot every op's output (NCHW fp32) into self.taps
+        self.taps = {}
         self.dtype = weights.dtype
         self.esz = 4 if self.dtype == _lib.F32 else 2
         self.bsrc = bsrc
@@ -149,6 +151,16 @@ class UNetPlan:
     # ---- launch recording ----
     def _rec(self, name, *args):
         self.launches.append((getattr(self.lib, name), name, args))
+
+    def _tap(self, name, act):
+        if not self.debug:
+            return
+        tdt = _TORCH_DT[self.dtype]
+        nbytes = act.n * act.side * act.side * act.c * self.esz
+
+        def snap(buf=act.buf, shape=(act.n, act.side, act.side, act.c)):
+            self.taps[name] = buf[:nbytes].view(tdt).view(shape).permute(0, 3, 1, 2).float().clone()
+        self.launches.append((None, name, snap))
 
     def _f32(self, *shape):
         t = torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -258,6 +270,7 @@ class UNetPlan:
         h = self._new(n, S, sp.stem_out)
         self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9)
         self.arena.put(xin.buf)
+        self._tap("stem", h)
         stash = [h]
         # ---- encoder / bottleneck / decoder ----
         for st in sp.stages:
@@ -271,6 +284,7 @@ class UNetPlan:
                     h = self._res(op, prev, skip if first else None)
                 else:
                     h = self._attn(op, prev)
+                self._tap(op.prefix, h)
                 # the stage input may still be referenced by the skip stash; intermediates are not
                 if not any(prev is s for s in stash):
                     self.arena.put(prev.buf)
@@ -291,6 +305,9 @@ class UNetPlan:
     def _enqueue(self, stream):
         sp = C.c_void_p(stream)
         for fn, name, args in self.launches:
+            if fn is None:
+                args()
+                continue
             st = fn(*args, sp)
             if st != 0:
                 _lib.check(st, name)
@@ -314,7 +331,7 @@ class UNetPlan:
     def launch(self, use_graph=True):
         """Enqueue one forward on self.stream from the static input buffers (no host sync)."""
         stream = self.stream.cuda_stream
-        if not use_graph or not self.warm:
+        if self.debug or not use_graph or not self.warm:
             self._enqueue(stream)   # first run is eager: sets kernel attributes, creates the zero page
             self.warm = True
             return
@@ -328,6 +345,33 @@ class UNetPlan:
             _lib.check(st, "ivid_graph_end")
             self.graph = gh
         _lib.call("ivid_graph_launch", self.graph, C.c_void_p(stream))
+
+    def profile_eager(self):
+        """One eager forward with a HIP-event pair around EVERY launch (on the plan's stream, where the
+        kernels run).  Returns [(c_abi_name, args, milliseconds)] — bench.py derives the per-kernel-family
+        roofline numbers from it; rocprofv3 --kernel-trace --stats must agree (profiles/)."""
+        stream = C.c_void_p(self.stream.cuda_stream)
+        evs = []
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.stream(self.stream):
+            for fn, name, args in self.launches:
+                if fn is None:
+                    continue
+                e0, e1 = C.c_void_p(), C.c_void_p()
+                _lib.call("ivid_event_create", C.byref(e0))
+                _lib.call("ivid_event_create", C.byref(e1))
+                _lib.call("ivid_event_record", e0, stream)
+                _lib.check(fn(*args, stream), name)
+                _lib.call("ivid_event_record", e1, stream)
+                evs.append((name, args, e0, e1))
+        out = []
+        for name, args, e0, e1 in evs:
+            ms = C.c_float()
+            _lib.call("ivid_event_elapsed_ms", e0, e1, C.byref(ms))
+            out.append((name, args, ms.value))
+            _lib.call("ivid_event_destroy", e0)
+            _lib.call("ivid_event_destroy", e1)
+        return out
 
     def __del__(self):
         try:

@@ -1,0 +1,95 @@
+"""Sample-parallel multi-GPU support: one process per GPU, NO collective inside the denoise loop.
+
+Reference: inference/sample.py:199-202 partitions seeds / classes / output indices / per-sample camera
+lists rank-strided (`x[rank::world_size]`) and every rank torch.load()s both checkpoints itself
+(sample.py:186,194).  Here the partition is identical, and the checkpoints are read once by rank 0 and
+broadcast as ONE packed fp32 blob per model over RCCL/xGMI (torch.distributed backend "nccl"; the
+reference's own precedent is trainers/utils.py:11-37 read_file_dist).  1.6 GiB at one-link xGMI speed
+(~153 GB/s) is ~11 ms — start-up only.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun-style env vars (RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return rank_world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+    return rank_world()
+
+
+def shard(seq, rank=None, world=None):
+    """Rank-strided shard, exactly `seq[rank::world_size]` (sample.py:199-202); None passes through."""
+    if seq is None:
+        return None
+    if rank is None:
+        rank, world = rank_world()
+    return seq[rank::world]
+
+
+def shard_views(modelviews, rank=None, world=None):
+    """Per-sample camera lists are sharded, a shared camera list is not (sample.py:202)."""
+    if modelviews and isinstance(modelviews[0], list):
+        return shard(modelviews, rank, world)
+    return modelviews
+
+
+def broadcast_state_dict(schema, state_dict=None, device=None, src=0):
+    """Broadcast a checkpoint from `src` to every rank as one flat fp32 message.
+
+    schema: [(name, shape)] known on every rank (derived from the config, so no metadata exchange);
+    state_dict: the loaded checkpoint on `src`, ignored elsewhere.  Returns {name: tensor} on `device`.
+    """
+    rank, world = rank_world()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    sizes = []
+    for _, shape in schema:
+        n = 1
+        for s in shape:
+            n *= s
+        sizes.append(n)
+    total = sum(sizes)
+    if rank == src:
+        missing = [n for n, _ in schema if n not in state_dict]
+        if missing:
+            raise KeyError(f"checkpoint lacks {missing[:3]}...")
+        flat = torch.cat([state_dict[n].detach().reshape(-1).to(torch.float32) for n, _ in schema]).to(device)
+        assert flat.numel() == total
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+    if world > 1:
+        dist.broadcast(flat, src=src)
+    out, off = {}, 0
+    for (name, shape), n in zip(schema, sizes):
+        out[name] = flat[off:off + n].view(shape)
+        off += n
+    return out
+
+
+def gather_scalars(value):
+    """all_gather of one float per rank (timings / counters at the end of a run)."""
+    rank, world = rank_world()
+    if world == 1:
+        return [float(value)]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]

@@ -76,7 +76,7 @@ def attnblock(sd, p, x, head_channels, groups):
     return (xf + a).reshape(b, c, hh, ww)
 
 
-def _stage(sd, prefix, h, emb, args, res_modes):
+def _stage(sd, prefix, h, emb, args, res_modes, trace=None):
     """Run the sub-layers prefix.0, prefix.1, ... of one ModSequential (adm.py:55-66)."""
     j = 0
     while True:
@@ -87,6 +87,8 @@ def _stage(sd, prefix, h, emb, args, res_modes):
             h = attnblock(sd, p, h, args["num_head_channels"], args["num_groups"])
         else:
             return h
+        if trace is not None:
+            trace[p] = h
         j += 1
 
 
@@ -115,7 +117,7 @@ def _updown_modes(sd, args):
 
 
 @torch.no_grad()
-def unet_forward(sd, args, x, t, classes=None):
+def unet_forward(sd, args, x, t, classes=None, trace=None):
     """adm.py:526-566 in fp32.  sd: bare state_dict (fp32 CPU); args: configs/*.json:backbone.args."""
     sd = {k: v.float() for k, v in sd.items()}
     has_null = bool(args.get("has_null_class", False)) and args.get("num_classes") is not None
@@ -124,16 +126,18 @@ def unet_forward(sd, args, x, t, classes=None):
     hs = []
     h = F.conv2d(x.float(), sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1)
     hs.append(h)
+    if trace is not None:
+        trace["stem"] = h
     i = 1
     while f"input_blocks.{i}.0.in_layers.0.weight" in sd:
-        h = _stage(sd, f"input_blocks.{i}", h, emb, args, modes)
+        h = _stage(sd, f"input_blocks.{i}", h, emb, args, modes, trace)
         hs.append(h)
         i += 1
-    h = _stage(sd, "middle_block", h, emb, args, modes)
+    h = _stage(sd, "middle_block", h, emb, args, modes, trace)
     i = 0
     while f"output_blocks.{i}.0.in_layers.0.weight" in sd:
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _stage(sd, f"output_blocks.{i}", h, emb, args, modes)
+        h = _stage(sd, f"output_blocks.{i}", h, emb, args, modes, trace)
         i += 1
     h = F.silu(gn32(h, sd["out.0.weight"], sd["out.0.bias"], args["num_groups"]))
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)

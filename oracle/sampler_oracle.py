@@ -96,9 +96,9 @@ def ddim_sample(eps_fn, x_T, steps, betas, eta=0.0, clip_denoised=False, replace
 
 
 @torch.no_grad()
-def ddpm_sample(eps_fn, x_T, betas, clip_denoised=False, t_stop=0):
-    """ddpm.py:43-187 (fixed-small variance, clipped log-variance).  `t_stop` > 0 truncates the chain
-    for cheap tests: steps T-1 ... t_stop are run."""
+def ddpm_sample(eps_fn, x_T, betas, clip_denoised=False, t_start=None, t_stop=0):
+    """ddpm.py:43-187 (fixed-small variance, clipped log-variance).  `t_start` / `t_stop` restrict the
+    chain to steps t_start ... t_stop (default T-1 ... 0) for single-step tests."""
     T = len(betas)
     alphas = 1.0 - betas
     ac = np.cumprod(alphas)
@@ -111,7 +111,7 @@ def ddpm_sample(eps_fn, x_T, betas, clip_denoised=False, t_stop=0):
     B = x_T.shape[0]
     img = x_T
     out = {"pred_x_t": [], "pred_x_0": []}
-    for i in range(T - 1, t_stop - 1, -1):
+    for i in range(T - 1 if t_start is None else t_start, t_stop - 1, -1):
         t = torch.full((B,), i, dtype=torch.long)
         eps = eps_fn(img, t)
         x0 = _x(sr, t, img) * img - _x(srm1, t, img) * eps

@@ -1,0 +1,331 @@
+"""GPU parity of every C-ABI kernel against a plain PyTorch fp32 reference of the same op
+(the ops are the ones the oracle composes: F.conv2d / F.group_norm / softmax-attention / the sampler algebra).
+
+fp32 mode must agree to fp32 round-off; bf16 mode is compared against the same fp32 math applied
+to bf16-rounded inputs and weights, so the tolerance only covers accumulation order + output rounding.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common
+import gpu_util as G
+from oracle import adm_oracle, sampler_oracle
+
+pytestmark = pytest.mark.gpu
+DTYPES = [0, 1]  # IVID_F32, IVID_BF16
+
+
+def conv_ref(x0, x1, w, b, res, res_mode, dtype):
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    x, w = G.rounded(x, dtype), G.rounded(w, dtype)
+    y = F.conv2d(x.double(), w.double(), b.double() if b is not None else None, padding=w.shape[-1] // 2)
+    if res_mode == 1:
+        y = y + G.rounded(res, dtype).double()
+    elif res_mode == 2:
+        y = y + F.interpolate(G.rounded(res, dtype).double(), scale_factor=2, mode="nearest")
+    elif res_mode == 3:
+        y = y + F.avg_pool2d(G.rounded(res, dtype).double(), 2)
+    return y.float()
+
+
+def run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg):
+    L = G.lib()
+    N, C0, H, W = x0.shape
+    C1 = x1.shape[1] if x1 is not None else 0
+    Cout, _, k, _ = w.shape
+    taps = k * k
+    d0 = G.to_nhwc(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    bd = b.cuda() if b is not None else None
+    rd = G.to_nhwc(res, dtype) if res is not None else None
+    if out_mode == 0:
+        out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    else:
+        out = torch.full((N, Cout, H, W), float("nan"), device="cuda", dtype=torch.float32)
+    L.call("ivid_conv2d", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(rd), res_mode,
+           out_mode, N, H, W, Cout, taps, tile_cfg, G.stream())
+    torch.cuda.synchronize()
+    return G.from_nhwc(out) if out_mode == 0 else out.cpu()
+
+
+CONV_CASES = [
+    # name, N, H, W, C0, C1, Cout, k, res_mode, out_mode, tile_cfg
+    ("3x3_small_nmask", 2, 16, 16, 64, 0, 64, 3, 0, 0, 1),
+    ("3x3_concat_mmask", 3, 8, 8, 64, 128, 128, 3, 0, 0, 1),
+    ("1x1_res_same", 2, 16, 16, 128, 0, 256, 1, 1, 0, 1),
+    ("1x1_concat", 2, 8, 8, 128, 64, 128, 1, 0, 0, 1),
+    ("3x3_res_up", 2, 16, 16, 64, 0, 64, 3, 2, 0, 1),
+    ("3x3_res_down", 2, 8, 8, 64, 0, 64, 3, 3, 0, 1),
+    ("3x3_nchw_out4", 2, 16, 16, 64, 0, 4, 3, 0, 1, 1),
+    ("3x3_nonsquare", 1, 8, 16, 64, 0, 128, 3, 1, 0, 1),
+    ("linear_m5", 5, 1, 1, 256, 0, 1024, 1, 1, 0, 1),
+    ("3x3_bigtile", 2, 32, 32, 128, 0, 512, 3, 1, 0, 2),
+    ("3x3_bigtile_masks", 1, 24, 24, 64, 64, 320, 3, 0, 0, 2),
+    ("3x3_64px_auto", 1, 64, 64, 256, 0, 256, 3, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(case, dtype):
+    name, N, H, W, C0, C1, Cout, k, res_mode, out_mode, tile_cfg = case
+    if dtype == 0 and (C0 % 32 or C1 % 32):
+        pytest.skip("K-step")
+    s = sum(map(ord, name)) % 1000
+    x0 = common.seeded_randn(s, N, C0, H, W)
+    x1 = common.seeded_randn(s + 1, N, C1, H, W) if C1 else None
+    w = common.seeded_randn(s + 2, Cout, C0 + C1, k, k) / np.sqrt((C0 + C1) * k * k)
+    b = common.seeded_randn(s + 3, Cout) * 0.1
+    res = None
+    if res_mode == 1:
+        res = common.seeded_randn(s + 4, N, Cout, H, W)
+    elif res_mode == 2:
+        res = common.seeded_randn(s + 4, N, Cout, H // 2, W // 2)
+    elif res_mode == 3:
+        res = common.seeded_randn(s + 4, N, Cout, H * 2, W * 2)
+    got = run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg)
+    ref = conv_ref(x0, x1, w, b, res, res_mode, dtype)
+    e = common.rel_l2(got, ref)
+    G.report(f"conv/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype), f"{name}: rel_l2 {e}"
+
+
+def test_conv2d_is_transpose_detecting_identity_weights():
+    # A = asymmetric ramp, W = identity 1x1: out must equal in exactly (catches swapped C/D row/col maps)
+    N, H, W, Cc = 1, 16, 16, 128
+    x = torch.arange(N * Cc * H * W, dtype=torch.float32).reshape(N, Cc, H, W) % 251 - 125
+    w = torch.eye(Cc).reshape(Cc, Cc, 1, 1)
+    for dtype in DTYPES:
+        got = run_conv(dtype, x, None, w, None, None, 0, 0, 1)
+        assert torch.equal(got, x), f"dtype {dtype}"
+
+
+def test_conv2d_rejects_bad_arguments_without_aborting():
+    L = G.lib()
+    x = torch.zeros(1, 4, 4, 48, device="cuda")
+    with pytest.raises(L.IvidHipError):
+        L.call("ivid_conv2d", 0, L.ptr(x), 48, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 9, 1, G.stream())
+    with pytest.raises(L.IvidHipError):
+        L.call("ivid_conv2d", 0, L.ptr(x), 64, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 4, 1, G.stream())
+
+
+GN_CASES = [
+    # name, N, H, C0, C1, resample, act, film
+    ("c64_same_silu", 2, 16, 64, 0, 0, 1, False),
+    ("c128+64_straddle_film", 2, 8, 128, 64, 0, 1, True),
+    ("c256_up", 2, 8, 256, 0, 1, 1, False),
+    ("c256_down_film", 2, 16, 256, 0, 2, 1, True),
+    ("c512_identity_attn_norm", 1, 32, 512, 0, 0, 0, False),
+    ("c2048_wide", 2, 8, 1024, 1024, 0, 1, False),
+    ("c384_ppc256", 1, 64, 384, 0, 0, 1, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
+def test_groupnorm_film_silu_resample(case, dtype):
+    name, N, H, C0, C1, resample, act, film = case
+    L = G.lib()
+    Cc = C0 + C1
+    s = sum(map(ord, name)) % 1000
+    x0 = common.seeded_randn(s, N, C0, H, H) * 1.7 + 0.3
+    x1 = common.seeded_randn(s + 1, N, C1, H, H) * 0.6 - 0.2 if C1 else None
+    gamma = 1 + 0.2 * common.seeded_randn(s + 2, Cc)
+    beta = 0.2 * common.seeded_randn(s + 3, Cc)
+    stride = 2 * Cc + 24
+    filmrow = 0.3 * common.seeded_randn(s + 4, N, stride)
+    off = 16
+    # reference (adm.py:36-41, 214-218, 203-208)
+    x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if film:
+        y = y * (1 + filmrow[:, off:off + Cc, None, None]) + filmrow[:, off + Cc:off + 2 * Cc, None, None]
+    if act:
+        y = F.silu(y)
+    if resample == 1:
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    elif resample == 2:
+        y = F.avg_pool2d(y, 2)
+    d0 = G.to_nhwc(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
+    HW = H * H
+    nch = L.load().ivid_gn_num_chunks(HW)
+    partial = torch.full((N, nch, Cc, 2), float("nan"), device="cuda")
+    ab = torch.full((N, Cc, 2), float("nan"), device="cuda")
+    Ho = y.shape[-1]
+    out = torch.full((N, Ho, Ho, Cc), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    g_d, b_d, f_d = gamma.cuda(), beta.cuda(), filmrow.cuda()
+    L.call("ivid_gn_partial", dtype, L.ptr(d0), C0, L.ptr(d1), C1, N, HW, L.ptr(partial), G.stream())
+    L.call("ivid_gn_finalize", L.ptr(partial), nch, N, Cc, HW, 32, 1e-5, L.ptr(g_d), L.ptr(b_d),
+           L.ptr(f_d) if film else None, stride, off, L.ptr(ab), G.stream())
+    L.call("ivid_gn_apply", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), L.ptr(out), N, H, H, resample, act, G.stream())
+    torch.cuda.synchronize()
+    got = G.from_nhwc(out)
+    e = common.rel_l2(got, y)
+    G.report(f"gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, y))
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype, 1e-5, 5e-3), f"{name}: rel_l2 {e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,heads,N", [(64, 2, 3), (256, 2, 2), (1024, 1, 1), (4096, 1, 1)])
+def test_attention(T, heads, N, dtype):
+    L = G.lib()
+    Cc = heads * 64
+    qkv = common.seeded_randn(T + heads, N, 3 * Cc, T) * 1.5   # [N, 3C, T] reference layout
+    ref = adm_oracle.qkv_attention(G.rounded(qkv, dtype), heads)  # [N, C, T]
+    d = qkv.permute(0, 2, 1).contiguous().to("cuda", G.tdt(dtype))                 # [N, T, 3C]
+    out = torch.full((N, T, Cc), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    L.call("ivid_attention", dtype, L.ptr(d), L.ptr(out), N, T, heads, G.stream())
+    torch.cuda.synchronize()
+    got = out.float().permute(0, 2, 1).cpu()
+    e = common.rel_l2(got, ref)
+    G.report(f"attn/T{T}_h{heads}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype, 2e-5, 1.5e-2), f"T={T}: rel_l2 {e}"
+
+
+def test_attention_online_softmax_rescale_with_spiked_key():
+    # one key far above the rest, placed in a LATE tile: forces the running-max rescale of O and l
+    L = G.lib()
+    N, T, heads = 1, 256, 1
+    qkv = common.seeded_randn(77, N, 192, T) * 0.5
+    qkv[0, 64:128, 200] = qkv[0, 0:64, 5] * 40.0   # k[200] aligned with q[5]
+    ref = adm_oracle.qkv_attention(qkv, heads)
+    d = qkv.permute(0, 2, 1).contiguous().cuda()
+    out = torch.empty(N, T, 64, device="cuda")
+    L.call("ivid_attention", 0, L.ptr(d), L.ptr(out), N, T, heads, G.stream())
+    torch.cuda.synchronize()
+    assert common.rel_l2(out.permute(0, 2, 1).cpu(), ref) < 2e-5
+
+
+def test_embed_inputs_and_silu():
+    L = G.lib()
+    B, N, half, ed, ncls = 3, 6, 64, 256, 10
+    freqs = torch.exp(-np.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    table = common.seeded_randn(5, ncls, ed)
+    times = torch.tensor([999, 0, 37])
+    classes = torch.tensor([3, -1, 9])
+    pos = torch.full((N, 2 * half), float("nan"), device="cuda")
+    cls = torch.full((N, ed), float("nan"), device="cuda")
+    td, cd, fd, tb = times.cuda(), classes.cuda(), freqs.cuda(), table.cuda()
+    L.call("ivid_embed_inputs", L.ptr(td), L.ptr(cd), B, N, 3, L.ptr(fd), half, L.ptr(tb), ed, L.ptr(pos), L.ptr(cls), G.stream())
+    y = torch.empty_like(pos)
+    L.call("ivid_silu_f32", L.ptr(pos), L.ptr(y), pos.numel(), G.stream())
+    torch.cuda.synchronize()
+    ref_pos = adm_oracle.pos_encoding(times.repeat(2), freqs)
+    # sin/cos of arguments up to 999 rad: device libm differs from the host's by a few ulp of the ARGUMENT
+    assert (pos.cpu() - ref_pos).abs().max() < 2e-4
+    ref_cls = torch.zeros(N, ed)
+    ref_cls[0] = table[3]
+    ref_cls[2] = table[9]          # rows 3..5 are the stacked null-class half
+    assert torch.equal(cls.cpu(), ref_cls)
+    assert common.rel_l2(y.cpu(), F.silu(pos.cpu())) < 1e-6
+
+
+def _ddim_ref(x_t, eps_c, eps_u, s, betas, t, tp, eta, clip, rr, rd, cd, noise):
+    eps = (1 + s) * eps_c - s * eps_u if eps_u is not None else eps_c
+    torch.manual_seed(0)
+    # reuse the oracle's single step by running a 1-step "chain" with a fixed eps and injected noise
+    ac = np.cumprod(1 - betas); acp = np.append(1.0, ac[:-1])
+    f = lambda a: torch.tensor(np.float32(a))
+    x0 = f(np.sqrt(1 / ac[t - 1])) * x_t - f(np.sqrt(1 / ac[t - 1] - 1)) * eps
+    nz = 1.0 if tp != 0 else 0.0
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    if rr is not None:
+        w, rgb, m = rr
+        x0[:, :3] = (1 - nz) * x0[:, :3] + nz * ((w * rgb + (1 - w) * x0[:, :3]) * m + x0[:, :3] * (1 - m))
+    if rd:
+        w, d, m = rd
+        x0[:, 3:] = (w * d + (1 - w) * x0[:, 3:]) * m + x0[:, 3:] * (1 - m)
+        if cd:
+            cw, cv = cd
+            x0[:, 3:] = x0[:, 3:] * m + (cw * torch.maximum(x0[:, 3:], cv) + (1 - cw) * x0[:, 3:]) * (1 - m)
+    e2 = (f(np.sqrt(1 / ac[t - 1])) * x_t - x0) / f(np.sqrt(1 / ac[t - 1] - 1))
+    ab, abp = f(ac[t - 1]), f(acp[tp])
+    sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+    xp = torch.sqrt(abp) * x0 + torch.sqrt(1 - abp - sigma ** 2) * e2 + nz * sigma * noise
+    return xp, x0
+
+
+@pytest.mark.parametrize("t,tp,eta,clip,cond,cfg", [(1000, 980, 0.0, False, False, True), (500, 480, 0.7, True, True, True),
+                                                    (20, 0, 0.5, False, True, False)])
+def test_ddim_step_kernel(t, tp, eta, clip, cond, cfg):
+    from ivid_amd.diffusion import frameworks, samplers
+
+    class Dummy:
+        image_size, out_channels = 16, 4
+        def forward(self, x, times, classes=None):
+            return x
+    B, S = 3, 16
+    smp = samplers.DdimSampler(frameworks.GaussianDiffusion(Dummy()))
+    L = G.lib()
+    r = lambda i, *s: common.seeded_randn(1000 + i, *s)
+    x_t, ec, eu, noise = r(1, B, 4, S, S), r(2, B, 4, S, S), r(3, B, 4, S, S), r(4, B, 4, S, S)
+    rgb, dep, cv = r(5, B, 3, S, S), r(6, B, 1, S, S), r(7, B, 1, S, S)
+    m = (r(8, B, 1, S, S) > 0).float()
+    mr = m * (r(9, B, 1, S, S) > 0).float()
+    k = smp._coef(t, tp, eta, 0.5 if cfg else 0.0, clip, 0.1 if cond else -1, 0.2 if cond else -1, 0.5 if cond else -1)
+    c = lambda a: a.cuda().contiguous()
+    dx, dec, deu, dn = c(x_t), c(ec), (c(eu) if cfg else None), c(noise)
+    drgb, dmr, ddep, dm, dcv = c(rgb), c(mr), c(dep), c(m), c(cv)
+    xp, x0 = torch.empty_like(dx), torch.empty_like(dx)
+    L.call("ivid_ddim_step", L.ptr(dx), L.ptr(dec), L.ptr(deu), C.byref(k), L.ptr(drgb) if cond else None,
+           L.ptr(dmr) if cond else None, L.ptr(ddep) if cond else None, L.ptr(dm) if cond else None,
+           L.ptr(dcv) if cond else None, L.ptr(dn), L.ptr(xp), L.ptr(x0), B, S * S, G.stream())
+    torch.cuda.synchronize()
+    rxp, rx0 = _ddim_ref(x_t.clone(), ec, eu if cfg else None, 0.5, sampler_oracle.linear_betas(1000), t, tp, eta, clip,
+                         (0.1, rgb, mr) if cond else None, (0.2, dep, m) if cond else None, (0.5, cv) if cond else None, noise)
+    assert common.rel_l2(x0.cpu(), rx0) < 2e-6 and common.rel_l2(xp.cpu(), rxp) < 2e-5
+
+
+def test_ddpm_step_and_inpaint_cond_kernels():
+    from ivid_amd.diffusion import frameworks, samplers
+
+    class Dummy:
+        image_size, out_channels = 16, 4
+        def forward(self, x, times, classes=None):
+            return x
+    L = G.lib()
+    B, S = 2, 16
+    r = lambda i, *s: common.seeded_randn(2000 + i, *s)
+    betas = sampler_oracle.linear_betas(1000)
+    smp = samplers.DdpmSampler(frameworks.GaussianDiffusion(Dummy()))
+    x_t, ec, eu, noise = r(1, B, 4, S, S), r(2, B, 4, S, S), r(3, B, 4, S, S), r(4, B, 4, S, S)
+    for t in (999, 1, 0):
+        k = smp._coef(t, 3.0, False)
+        d = [a.cuda() for a in (x_t, ec, eu, noise)]
+        xp, x0 = torch.empty_like(d[0]), torch.empty_like(d[0])
+        L.call("ivid_ddpm_step", L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), C.byref(k), L.ptr(d[3]), L.ptr(xp), L.ptr(x0), B, S * S, G.stream())
+        torch.cuda.synchronize()
+        eps = 4.0 * ec - 3.0 * eu
+        torch.manual_seed(0)
+        fixed = iter([noise])
+        import unittest.mock as um
+        with um.patch("torch.randn_like", lambda a: noise):
+            o = sampler_oracle.ddpm_sample(lambda x, tt: eps, x_t, betas, t_start=t, t_stop=t)
+        assert common.rel_l2(x0.cpu(), o["pred_x_0"][0]) < 2e-6, t
+        assert common.rel_l2(xp.cpu(), o["samples"]) < 2e-5, t
+    # InpaintCFG.make_cond_inputs
+    x, y = r(5, B, 4, S, S), r(6, B, 4, S, S)
+    m = (r(7, B, 1, S, S) > 0).float()
+    mr = m * (r(8, B, 1, S, S) > 0).float()
+    n3, n1 = r(9, B, 3, S, S), r(10, B, 1, S, S)
+    for use_mr in (True, False):
+        out = torch.full((B, 10 if use_mr else 9, S, S), float("nan"), device="cuda")
+        d = [a.cuda() for a in (x, y, m, mr, n3, n1)]
+        L.call("ivid_inpaint_cond", L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]) if use_mr else None, L.ptr(d[4]),
+               L.ptr(d[5]), L.ptr(out), B, S * S, G.stream())
+        torch.cuda.synchronize()
+        it = iter([n3, n1])
+        import unittest.mock as um
+        with um.patch("torch.randn_like", lambda a: next(it)):
+            ref = sampler_oracle.inpaint_inputs(x, y, m, mr if use_mr else None)
+        assert common.rel_l2(out.cpu(), ref) < 1e-6

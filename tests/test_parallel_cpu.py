@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: rank-strided sharding and the one-shot checkpoint broadcast."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import common as C
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, C.ROOT)
+    from ivid_amd import parallel
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env("gloo")
+    schema = C.schema_for(C.MINI)
+    sd = C.synth_weights(C.MINI, 0) if rank == 0 else None
+    got = parallel.broadcast_state_dict(schema, sd, device=torch.device("cpu"))
+    ref = C.synth_weights(C.MINI, 0)
+    same = all(torch.equal(got[k], ref[k]) for k in ref)
+    seeds = list(range(9))
+    views = [[i, i + 100] for i in range(9)]
+    mine = parallel.shard(seeds)
+    times = parallel.gather_scalars(1.5 + rank)
+    q.put((rank, same, mine, parallel.shard_views(views), parallel.shard_views([1, 2, 3]), times))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_broadcast():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == [0, 2, 4, 6, 8] and res[1][2] == [1, 3, 5, 7]          # seeds[rank::2] (sample.py:199)
+    assert sorted(res[0][2] + res[1][2]) == list(range(9))                      # disjoint cover
+    assert res[0][3] == [[0, 100], [2, 102], [4, 104], [6, 106], [8, 108]]      # per-sample views sharded
+    assert res[0][4] == [1, 2, 3] and res[1][4] == [1, 2, 3]                    # shared camera list not sharded
+    assert res[0][5] == [1.5, 2.5] and res[1][5] == [1.5, 2.5]
+
+
+def test_single_process_paths():
+    from ivid_amd import parallel
+    assert parallel.rank_world() == (0, 1)
+    assert parallel.shard([1, 2, 3]) == [1, 2, 3] and parallel.shard(None) is None
+    sd = C.synth_weights(C.MINI_UNCLASS, 3)
+    out = parallel.broadcast_state_dict(C.schema_for(C.MINI_UNCLASS), sd, device=torch.device("cpu"))
+    assert all(torch.equal(out[k], sd[k]) for k in sd)
