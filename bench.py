@@ -163,13 +163,30 @@ def main():
             "share_of_forward_time": round(conv["ms"] / total_ms, 4),
         }
         result["kernel_time_ms_per_forward"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items())}
+        if os.environ.get("IVID_BENCH_LAYERS"):  # per-launch table for kernel tuning (not part of the bench line)
+            rows = []
+            for name, args, ms in prof:
+                if name == "ivid_conv2d":
+                    fl, _ = conv_flops(args)
+                    rows.append(dict(n=args[11], h=args[12], cin=args[2] + args[4], cout=args[14], taps=args[15],
+                                     res=args[9], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+                elif name in ("ivid_gn_apply", "ivid_gn_partial", "ivid_attention"):
+                    rows.append(dict(op=name, args=[a for a in args if isinstance(a, int) and a < (1 << 32)], ms=round(ms, 4)))
+            with open(os.environ["IVID_BENCH_LAYERS"], "w") as f:
+                json.dump(rows, f, indent=0)
         result["forward_ms_eager_events"] = round(total_ms, 3)
 
     if rank == 0 and not a.no_cpu_baseline:
         # the oracle (a CPU restatement of the reference forward, pinned to it bit-for-bit by tests/golden) on the
         # host cores: 1 warm-up + 2 timed forwards at bs 2, fp32
         from oracle import adm_oracle
-        ncores = os.cpu_count()
+        # threads actually usable by this process (cgroup/affinity), capped: torch's CPU kernels stop scaling (and
+        # oversubscribe badly) far below the 256 logical cores of the GPU host
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except Exception:
+            avail = os.cpu_count()
+        ncores = max(1, min(avail, int(os.environ.get("IVID_CPU_BASELINE_THREADS", "32"))))
         torch.set_num_threads(ncores)
         sd_cpu = C.synth_weights(margs, 0)
         xb = C.seeded_randn(5, 2, 4, 128, 128)
