@@ -127,6 +127,48 @@ int ivid_ddpm_step(const float* x_t, const float* eps_c, const float* eps_u, con
 int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const float* mask_rgb, const float* noise_rgb,
                       const float* noise_depth, float* out, int B, int HW, void* stream);
 
+/* ---- RGBD depth-warp conditioning (replaces rgbd_3d + the moderngl/OpenGL renderer) ----
+ * Step 1, per generated view: depth -> textured grid mesh with frustum skirt (rgbd_3d/utils.py:144-260
+ * depth_to_mesh(padding='frustum', cal_normal=True), linearize_depth :38-58, unproject :89-110,
+ * triangulate :113-134, mask_discontinuity :137-141, cal_depth_normal :263-274), batched over B samples.
+ *   rgbd          : fp32 [B,4,S,S] network output in [-1,1] (RGB + z-buffer depth, inference/sample.py:83,126)
+ *   inv_modelview : fp32 [B][16] row-major camera->world matrix (glm.inverse(modelview), utils.py:232-237)
+ *   verts         : out fp32 [B][(S+2)^2][9] = world position(3), world normal(3), uv(2), flag(1) with
+ *                   flag = 1*discontinuity + 2*padding + 4*eroded (utils.py:249) — the reference's VBO layout
+ *                   (moderngl_renderer.py:284-290)
+ *   diag          : out u8 [B][(S+1)^2], 1 = quad split along its 00-11 diagonal (the index buffer is implicit)
+ *   colors        : out fp32 [B][S][S][3] RGB in [0,1] (the NEAREST texture, moderngl_renderer.py:293)
+ *   scratch_depth : fp32 [B][(S+2)^2]; scratch_flags: int32 [B][(S+2)^2] */
+int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview, float fov_deg, float nearv,
+                    float farv, float atol, float rtol, int erode, float* verts, unsigned char* diag, float* colors,
+                    float* scratch_depth, int* scratch_flags, void* stream);
+/* Step 2, per target view: z-buffered rasterisation of every source-view mesh ALONE (depth test '<', no cull,
+ * moderngl_renderer.py:198-202,307-312; aggregation.vsh/.fsh) + weighted aggregation across source views
+ * (clear.csh, aggregation.csh) + the read-back math of AggregationRenderer.render (:317-331), image row 0 = top.
+ *   verts/diag/colors : [NV][B][...] as produced by ivid_mesh_build for source views 0..NV-1
+ *   campos  : fp32 [NV][B][3] source camera positions (u_sample_camera = inverse(mv_i)[3], :310-311)
+ *   mvp     : fp32 [B][16] row-major projection * modelview of the TARGET view
+ *   R       : render size (S * ssaa);  rnear/rfar: the renderer's own planes (0.01 / 200, :161)
+ *   zbuf    : scratch u64 [NV][B][R*R]
+ *   outputs : color8 u8 [B][R][R][3] (to8b of the resolved colour), depth_lin fp32 [B][R][R] (metric depth),
+ *             mask_color / mask_depth u8 [B][R][R] */
+int ivid_warp_render(const float* verts, const unsigned char* diag, const float* colors, const float* campos, int NV,
+                     int B, int S, const float* mvp, int R, float rnear, float rfar, unsigned long long* zbuf,
+                     unsigned char* color8, float* depth_lin, unsigned char* mask_color, unsigned char* mask_depth,
+                     void* stream);
+/* Step 3: aggregate_conditions' SSAA resolve (rgbd_3d/utils.py:450-467): Pillow-exact 8-bit LANCZOS R->S
+ * (two integer passes; bounds int32 [S][2], coeffs int32 [S][ksize] with 22 fractional bits computed by the host),
+ * centre-sample depth + project_depth (:61-67), masks > 75 % of the ssaa^2 sub-pixels, depth_edge (:311-332),
+ * cv2.erode((2*erode-1)^2) of the depth mask into the colour mask, masked colour/depth.
+ *   lut255 : fp32 [256] = float32(i / 255.0);   tmp_h u8 [B][R][S][3]; tmp_small u8 [B][S][S][3];
+ *   tmp_dproj fp32 [B][S][S]; tmp_masks u8 [3][B][S][S]
+ *   outputs (all in [0,1], fp32): color [B,3,S,S], depth [B,1,S,S], mask [B,1,S,S], mask_rgb [B,1,S,S], convex [B,1,S,S] */
+int ivid_warp_resolve(const unsigned char* color8, const float* depth_lin, const unsigned char* mask_color,
+                      const unsigned char* mask_depth, int B, int S, int ssaa, const int* bounds, const int* coeffs,
+                      int ksize, const float* lut255, float nearv, float farv, float atol, float rtol, int erode,
+                      unsigned char* tmp_h, unsigned char* tmp_small, float* tmp_dproj, unsigned char* tmp_masks,
+                      float* color, float* depth, float* mask, float* mask_rgb, float* convex, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
