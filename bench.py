@@ -34,7 +34,7 @@ GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56}  # BASELINE.md §2 (2 
 
 def conv_flops(args):
     """Algorithmic FLOPs of one ivid_conv2d launch from its recorded arguments (2 x MACs)."""
-    (dtype, _s0, c0, _s1, c1, _w, _b, _o, _r, _rm, _om, n, h, w, cout, taps, _tc) = args
+    (dtype, _s0, c0, _s1, c1, _w, _b, _o, _r, _rm, _om, n, h, w, cout, taps, _tc, _st) = args
     return 2.0 * n * h * w * cout * taps * (c0 + c1), dtype
 
 

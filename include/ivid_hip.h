@@ -47,10 +47,15 @@ int ivid_event_destroy(void* ev);
  *   res_mode  : 0 none; 1 add res[N,H,W,Cout]; 2 add nearest-x2-upsampled res[N,H/2,W/2,Cout];
  *               3 add 2x2-avg-pooled res[N,2H,2W,Cout]  (ResBlock2d skip through x_upd, adm.py:203-208,222)
  *   out_mode  : 0 NHWC dtype [N,H,W,Cout]; 1 fp32 NCHW [N,Cout,H,W] (final conv, adm.py:566)
- *   tile_cfg  : 0 auto, 1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves */
+ *   tile_cfg  : 0 auto, 1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 3 = 128x32 tile (narrow Cout);
+ *               +16 = tap-major K loop (tuning only; default is channel-chunk-major so the 9 taps of a 3x3 re-read
+ *               their slab from L2)
+ *   stats     : NULL, or fp32 [N*H*W/32][Cout][2]: per 32-pixel row block and output channel, sum and sum of squares
+ *               of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this epilogue
+ *               (same layout as ivid_gn_partial with H*W/32 chunks per image) */
 int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias,
                 void* out, const void* res, int res_mode, int out_mode, int N, int H, int W, int Cout, int taps,
-                int tile_cfg, void* stream);
+                int tile_cfg, float* stats, void* stream);
 
 /* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
  * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).
@@ -65,6 +70,11 @@ int ivid_gn_partial(int dtype, const void* src0, int C0, const void* src1, int C
 int ivid_gn_finalize(const float* partial, int nchunks, int N, int C, int HW, int groups, float eps,
                      const float* gamma, const float* beta, const float* film, int film_stride, int film_off,
                      float* ab, void* stream);
+/* Same, with the statistics of a skip concat kept as two separate partial buffers (one per source tensor, as the
+ * producing convolutions' epilogues wrote them): partial0 [N][nchunks][C0][2], partial1 [N][nchunks][C1][2]. */
+int ivid_gn_finalize2(const float* partial0, int C0, const float* partial1, int C1, int nchunks, int N, int HW,
+                      int groups, float eps, const float* gamma, const float* beta, const float* film,
+                      int film_stride, int film_off, float* ab, void* stream);
 /* Step 3: out = act(x*a+b) with optional resampling folded in (adm.py:203-208):
  *   resample 0: same size; 1: nearest x2 upsample (out is 2H x 2W); 2: 2x2 average pool of the ACTIVATED
  *   values (out is H/2 x W/2).  act: 0 identity (AttentionBlock.norm, adm.py:283), 1 SiLU.

@@ -45,6 +45,8 @@ struct ConvArgs {
   int M;
   int ntiles_n;
   int ntiles_total;
+  int korder;    // 0: tap-major K loop (tap outer, channel chunk inner); 1: chunk-major (chunk outer, tap inner)
+  float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
 };
 
 template <typename T> struct Mma;
@@ -142,9 +144,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
       glds16(g, sB + (i * NT + wave * 64) * 16);
     }
-    if (++ld_ch == chunks) {
-      ld_ch = 0;
-      ++ld_tap;
+    // K-loop order.  Chunk-major keeps the 9 shifted re-reads of one 128-byte channel slab back to back, so they hit
+    // in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the full channel extent of the tile per tap
+    // (256 px x C x 2 B x 32 resident tiles > 4 MiB L2).  The sum over K is order-independent up to fp32 rounding.
+    if (p.korder == 0) {
+      if (++ld_ch == chunks) {
+        ld_ch = 0;
+        ++ld_tap;
+      }
+    } else {
+      if (++ld_tap == p.taps) {
+        ld_tap = 0;
+        ++ld_ch;
+      }
     }
   };
 
@@ -215,6 +227,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       constexpr int LPR = WTN / VE;   // lanes per slab row
       constexpr int RPP = 64 / LPR;   // rows per pass
       const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+      float st_s[VE], st_q[VE];       // GroupNorm partial statistics of this 32-row block (fused gn_partial)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
 #pragma unroll
       for (int ps = 0; ps < 32 / RPP; ++ps) {
         const int row = ps * RPP + lr;
@@ -262,7 +277,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
               for (int e = 0; e < VE; ++e) v[e] += 0.25f * s[e];
             }
           }
-          *(vec_t*)(p.out + ((size_t)m * Cout + n) * sizeof(T)) = f32_to_vec<T>(v);
+          const vec_t ov = f32_to_vec<T>(v);
+          *(vec_t*)(p.out + ((size_t)m * Cout + n) * sizeof(T)) = ov;
+          if (p.stats) {
+            float sv[VE];
+            vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+              st_s[e] += sv[e];
+              st_q[e] += sv[e] * sv[e];
+            }
+          }
+        }
+      }
+      if (p.stats) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            st_s[e] += __shfl_xor(st_s[e], off);
+            st_q[e] += __shfl_xor(st_q[e], off);
+          }
+        }
+        const int n = nbase + lc;
+        if (lr == 0 && mbase < p.M && n < Cout) {
+          float* sp = p.stats + ((size_t)(mbase >> 5) * Cout + n) * 2;
+#pragma unroll
+          for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
         }
       }
     } else {  // fp32 NCHW output (small Cout): lanes run along pixels for coalescing
@@ -307,7 +348,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 
 extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
                            const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
-                           int W, int Cout, int taps, int tile_cfg, void* stream) {
+                           int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
   const int esz = dtype == IVID_F32 ? 4 : 2;
   const int bke = 128 / esz, ve = 16 / esz;
   if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv: bad dtype", hipSuccess);
@@ -324,16 +365,22 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (!a.zero) return -1;
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
+  if (stats && (out_mode != 0 || ((long long)N * H * W) % 32)) return ivid_set_error("conv: stats need NHWC output and M % 32 == 0", hipSuccess);
+  a.stats = stats;
+  a.korder = (tile_cfg & 16) ? 0 : 1;   // bit 4 of tile_cfg selects the legacy tap-major order (A/B testing)
+  tile_cfg &= 15;
   hipStream_t s = (hipStream_t)stream;
-  if (tile_cfg == 0) {  // auto: big tile when it still fills the chip
+  if (tile_cfg == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
-    tile_cfg = (Cout >= 256 && big >= 512) ? 2 : 1;
+    tile_cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1);
   }
   if (dtype == IVID_BF16) {
     if (tile_cfg == 2) return launch_conv<__bf16, 256, 256, 2, 4>(a, s);
+    if (tile_cfg == 3) return launch_conv<__bf16, 128, 32, 4, 1>(a, s);
     return launch_conv<__bf16, 128, 128, 2, 2>(a, s);
   } else {
     if (tile_cfg == 2) return launch_conv<float, 256, 256, 2, 4>(a, s);
+    if (tile_cfg == 3) return launch_conv<float, 128, 32, 4, 1>(a, s);
     return launch_conv<float, 128, 128, 2, 2>(a, s);
   }
 }

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int C0,
+                                                         const float* __restrict__ partial1, int nchunks, int C,
                                                          int HW, int groups, float eps,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
@@ -98,12 +99,15 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
                                                          int film_off, float* __restrict__ ab) {
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int cpg = C / groups;
-  const float* pp = partial + (size_t)n * nchunks * C * 2;
+  const int C1 = C - C0;
+  const float* pp0 = partial + (size_t)n * nchunks * C0 * 2;
+  const float* pp1 = partial1 ? partial1 + (size_t)n * nchunks * C1 * 2 : nullptr;
   double s = 0.0, ss = 0.0;
   for (int idx = t; idx < nchunks * cpg; idx += 64) {
     const int ch = idx / cpg, c = g * cpg + (idx - ch * cpg);
-    s += (double)pp[((size_t)ch * C + c) * 2];
-    ss += (double)pp[((size_t)ch * C + c) * 2 + 1];
+    const float* q = c < C0 ? pp0 + ((size_t)ch * C0 + c) * 2 : pp1 + ((size_t)ch * C1 + (c - C0)) * 2;
+    s += (double)q[0];
+    ss += (double)q[1];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -236,9 +240,20 @@ extern "C" int ivid_gn_finalize(const float* partial, int nchunks, int N, int C,
                                 const float* gamma, const float* beta, const float* film, int film_stride,
                                 int film_off, float* ab, void* stream) {
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize: C must be divisible by groups", hipSuccess);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial, nchunks, C, HW,
-                     groups, eps, gamma, beta, film, film_stride, film_off, ab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial, C, nullptr, nchunks,
+                     C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize");
+}
+
+extern "C" int ivid_gn_finalize2(const float* partial0, int C0, const float* partial1, int C1, int nchunks, int N, int HW,
+                                 int groups, float eps, const float* gamma, const float* beta, const float* film,
+                                 int film_stride, int film_off, float* ab, void* stream) {
+  const int C = C0 + C1;
+  if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize2: C must be divisible by groups", hipSuccess);
+  if (C1 > 0 && !partial1) return ivid_set_error("gn_finalize2: partial1 missing", hipSuccess);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks,
+                     C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
+  return ivid_check_launch("gn_finalize2");
 }
 
 extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, void* out,

@@ -33,9 +33,11 @@ struct MeshParams {
 // linear (metric) depth of pixel (r,c) in fp32, as inference/sample.py:83,126 + linearize_depth do
 __device__ __forceinline__ float lin_depth(const float* rgbd, const MeshParams& m, int b, int r, int c) {
   const int S = m.S;
-  float d = rgbd[((size_t)b * 4 + 3) * S * S + (size_t)r * S + c] * 0.5f + 0.5f;
+  // every operation rounded separately like numpy's float32 arithmetic (no FMA contraction): neighbouring depths
+  // differ by ~1e-3, so a 1-ulp change here shows up as 1e-5 in the normals
+  float d = __fadd_rn(__fmul_rn(rgbd[((size_t)b * 4 + 3) * S * S + (size_t)r * S + c], 0.5f), 0.5f);
   d = fminf(fmaxf(d, 1e-6f), 1.0f - 1e-6f);
-  return m.nearv * m.farv / (m.farv - (m.farv - m.nearv) * d);
+  return __fdiv_rn(__fmul_rn(m.nearv, m.farv), __fsub_rn(m.farv, __fmul_rn(__fsub_rn(m.farv, m.nearv), d)));
 }
 
 struct D3 { double x, y, z; };
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void mesh_points_kernel(const float* __restric
     const size_t px = (size_t)(pr - 1) * S + (pc - 1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-      colors[((size_t)b * S * S + px) * 3 + ch] = rgbd[((size_t)b * 4 + ch) * S * S + px] * 0.5f + 0.5f;
+      colors[((size_t)b * S * S + px) * 3 + ch] = __fadd_rn(__fmul_rn(rgbd[((size_t)b * 4 + ch) * S * S + px], 0.5f), 0.5f);
   }
 }
 

@@ -12,6 +12,7 @@ Data flow of a ResBlock (adm.py:192-222), all tensors NHWC:
     out = conv3x3(act2) + bias + skip      (skip = x, resampled x, or conv1x1(x|skip))
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -109,11 +110,12 @@ class _Arena:
 
 
 class _Act:
-    """An NHWC activation living in an arena buffer."""
-    __slots__ = ("buf", "n", "side", "c")
+    """An NHWC activation living in an arena buffer (+ optionally the GroupNorm partial statistics its producing
+    convolution wrote: fp32 [n*side*side/32][c][2])."""
+    __slots__ = ("buf", "n", "side", "c", "stats")
 
-    def __init__(self, buf, n, side, c):
-        self.buf, self.n, self.side, self.c = buf, n, side, c
+    def __init__(self, buf, n, side, c, stats=None):
+        self.buf, self.n, self.side, self.c, self.stats = buf, n, side, c, stats
 
     @property
     def ptr(self):
@@ -124,6 +126,7 @@ class UNetPlan:
     def __init__(self, spec: UNetSpec, weights: PackedWeights, device, bsrc, stacked, tile_cfg=0, debug=False):
         self.spec, self.w, self.device = spec, weights, device
         self.debug = debug      # eager-only: snapshot every op's output (NCHW fp32) into self.taps
+        self.fuse_stats = os.environ.get("IVID_NO_FUSED_STATS", "0") != "1"   # GN partials from conv epilogues
         self.taps = {}
         self.dtype = weights.dtype
         self.esz = 4 if self.dtype == _lib.F32 else 2
@@ -167,13 +170,21 @@ class UNetPlan:
         self._keep.append(t)
         return t
 
-    def _new(self, n, side, c):
-        return _Act(self.arena.get(n * side * side * c * self.esz), n, side, c)
+    def _new(self, n, side, c, stats=False):
+        """stats=True: the tensor will be GroupNorm'ed later -> its producer also emits the partial statistics."""
+        st = self.arena.get(n * side * side // 32 * c * 2 * 4) if (stats and self.fuse_stats) else None
+        return _Act(self.arena.get(n * side * side * c * self.esz), n, side, c, st)
 
-    def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps):
+    def _free(self, act):
+        self.arena.put(act.buf)
+        if act.stats is not None:
+            self.arena.put(act.stats)
+
+    def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
+              stats=None):
         self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
                   self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
-                  self.tile_cfg)
+                  self.tile_cfg, stats.data_ptr() if stats is not None else None)
 
     def _linear(self, x, k, wname, out, cout, res=None):
         self._conv(_lib.F32, x.data_ptr(), k, None, 0, wname, out.data_ptr(), res.data_ptr() if res is not None else None,
@@ -185,19 +196,27 @@ class UNetPlan:
         c0, c1 = x0.c, (x1.c if x1 is not None else 0)
         c = c0 + c1
         hw = side * side
-        nch = self.lib.ivid_gn_num_chunks(hw)
-        partial = self.arena.get(n * nch * c * 2 * 4)
         ab = self.arena.get(n * c * 2 * 4)
         p1 = x1.ptr if x1 is not None else None
-        self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, p1, c1, n, hw, partial.data_ptr())
         film = self.embproj.data_ptr() if film_off is not None else None
-        self._rec("ivid_gn_finalize", partial.data_ptr(), nch, n, c, hw, self.spec.num_groups, 1e-5,
-                  self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr(), film,
-                  self.spec.emb_total, film_off if film_off is not None else 0, ab.data_ptr())
+        fo = film_off if film_off is not None else 0
+        gw, gb = self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr()
+        partial = None
+        if x0.stats is not None and (x1 is None or x1.stats is not None):
+            # statistics came for free from the producers' epilogues (one buffer per concat source)
+            self._rec("ivid_gn_finalize2", x0.stats.data_ptr(), c0, x1.stats.data_ptr() if x1 is not None else None, c1,
+                      hw // 32, n, hw, self.spec.num_groups, 1e-5, gw, gb, film, self.spec.emb_total, fo, ab.data_ptr())
+        else:
+            nch = self.lib.ivid_gn_num_chunks(hw)
+            partial = self.arena.get(n * nch * c * 2 * 4)
+            self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, p1, c1, n, hw, partial.data_ptr())
+            self._rec("ivid_gn_finalize", partial.data_ptr(), nch, n, c, hw, self.spec.num_groups, 1e-5, gw, gb, film,
+                      self.spec.emb_total, fo, ab.data_ptr())
         so = {0: side, 1: side * 2, 2: side // 2}[resample]
         y = self._new(n, so, c)
         self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, p1, c1, ab.data_ptr(), y.ptr, n, side, side, resample, act)
-        self.arena.put(partial)
+        if partial is not None:
+            self.arena.put(partial)
         self.arena.put(ab)
         return y
 
@@ -207,13 +226,13 @@ class UNetPlan:
         resample = {"same": 0, "up": 1, "down": 2}[op.mode]
         act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
         so = op.res_out
-        h1 = self._new(n, so, op.cout)
+        h1 = self._new(n, so, op.cout, stats=True)
         self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
-                   op.cout, 9)
-        self.arena.put(act1.buf)
+                   op.cout, 9, stats=h1.stats)
+        self._free(act1)
         act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
-        self.arena.put(h1.buf)
-        out = self._new(n, so, op.cout)
+        self._free(h1)
+        out = self._new(n, so, op.cout, stats=True)
         if op.has_skip_conv:
             assert op.mode == "same"
             r = self._new(n, so, op.cout)
@@ -225,10 +244,10 @@ class UNetPlan:
             r = None
             res_ptr, res_mode = x.ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
         self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
-                   n, so, so, op.cout, 9)
-        self.arena.put(act2.buf)
+                   n, so, so, op.cout, 9, stats=out.stats)
+        self._free(act2)
         if r is not None:
-            self.arena.put(r.buf)
+            self._free(r)
         return out
 
     def _attn(self, op: Attn, x: _Act):
@@ -236,13 +255,14 @@ class UNetPlan:
         xn = self._gn(x, None, op.prefix + ".norm", None, 0, 0)
         qkv = self._new(n, side, 3 * c)
         self._conv(self.dtype, xn.ptr, c, None, 0, op.prefix + ".qkv", qkv.ptr, None, 0, 0, n, side, side, 3 * c, 1)
-        self.arena.put(xn.buf)
+        self._free(xn)
         a = self._new(n, side, c)
         self._rec("ivid_attention", self.dtype, qkv.ptr, a.ptr, n, side * side, op.heads)
-        self.arena.put(qkv.buf)
-        out = self._new(n, side, c)
-        self._conv(self.dtype, a.ptr, c, None, 0, op.prefix + ".proj_out", out.ptr, x.ptr, 1, 0, n, side, side, c, 1)
-        self.arena.put(a.buf)
+        self._free(qkv)
+        out = self._new(n, side, c, stats=True)
+        self._conv(self.dtype, a.ptr, c, None, 0, op.prefix + ".proj_out", out.ptr, x.ptr, 1, 0, n, side, side, c, 1,
+                   stats=out.stats)
+        self._free(a)
         return out
 
     def _build(self):
@@ -267,9 +287,10 @@ class UNetPlan:
         xin = self._new(n, S, w.cin_pad)
         self._rec("ivid_nchw_to_nhwc", self.dtype, self.x_in.data_ptr(), self.bsrc, n, sp.in_channels, S, S, w.cin_pad,
                   xin.ptr)
-        h = self._new(n, S, sp.stem_out)
-        self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9)
-        self.arena.put(xin.buf)
+        h = self._new(n, S, sp.stem_out, stats=True)
+        self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9,
+                   stats=h.stats)
+        self._free(xin)
         self._tap("stem", h)
         stash = [h]
         # ---- encoder / bottleneck / decoder ----
@@ -287,19 +308,19 @@ class UNetPlan:
                 self._tap(op.prefix, h)
                 # the stage input may still be referenced by the skip stash; intermediates are not
                 if not any(prev is s for s in stash):
-                    self.arena.put(prev.buf)
+                    self._free(prev)
                 if first and skip is not None:
-                    self.arena.put(skip.buf)
+                    self._free(skip)
                 first = False
             if st.kind == "in":
                 stash.append(h)
         assert not stash
         # ---- head: GN + SiLU + conv3x3 -> fp32 NCHW (adm.py:565-566) ----
         act = self._gn(h, None, "out.0", None, 0, 1)
-        self.arena.put(h.buf)
+        self._free(h)
         self._conv(self.dtype, act.ptr, sp.final_c, None, 0, "out.2", self.out.data_ptr(), None, 0, 1, n, S, S,
                    sp.out_channels, 9)
-        self.arena.put(act.buf)
+        self._free(act)
 
     # ---- execution ----
     def _enqueue(self, stream):

@@ -33,7 +33,6 @@ def sample_all(framework_uncond, framework_cond, seeds_or_num_samples, steps_unc
     num_samples = seeds_or_num_samples if not isinstance(seeds_or_num_samples, list) else len(seeds_or_num_samples)
     seeds = seeds_or_num_samples if isinstance(seeds_or_num_samples, list) else None
     is_cfg = isinstance(framework_uncond, frameworks.ClassifierFreeGuidance)
-    extra = {"noise_fn": noise_fn} if noise_fn is not None else {}
     renderers = {}
     for i in range(0, num_samples, batchsize):
         bs = min(batchsize, num_samples - i)
@@ -47,6 +46,17 @@ def sample_all(framework_uncond, framework_cond, seeds_or_num_samples, steps_unc
         else:
             noise = None
         b_classes = torch.tensor(classes[i:i + bs]).long().to(device) if classes is not None else None
+        # Noise inside the chain (hole noise of InpaintCFG, eta > 0, DDPM).  The reference draws it from the process-wide
+        # CUDA generator, so a sample's result depends on which other samples share its batch / GPU.  With seeds, every
+        # sample gets its own generator instead: results are invariant under the rank / batch partition.
+        if noise_fn is not None:
+            extra = {"noise_fn": noise_fn}
+        elif seeds is not None:
+            gens = [torch.Generator(device=device).manual_seed(0x5EED0000 + int(seeds[i + j])) for j in range(bs)]
+            extra = {"noise_fn": lambda shape, g=gens: torch.cat(
+                [torch.randn((1,) + tuple(shape[1:]), device=device, generator=gj) for gj in g], dim=0)}
+        else:
+            extra = {}
         if sampler_cond is not None:
             key = (bs, len(s_modelviews))
             if key not in renderers:

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Kernel-level microbenchmark of ivid_conv2d on the layer shapes of the large UNet at stacked batch 128 (HIP events
+on the launch stream).  Prints one line per (shape, tile_cfg): ms, TFLOP/s.  Tuning aid, not part of the bench contract."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from ivid_amd import _lib  # noqa: E402
+
+SHAPES = [  # (H, Cin, Cout, taps)
+    (128, 256, 256, 9), (128, 512, 256, 9), (128, 512, 256, 1), (64, 256, 256, 9), (64, 768, 256, 9), (32, 512, 512, 9),
+    (32, 1280, 512, 9), (32, 512, 1536, 1), (16, 768, 768, 9), (16, 1792, 768, 9), (8, 1024, 1024, 9), (8, 2048, 1024, 9),
+]
+
+
+def main():
+    n = int(os.environ.get("N", "128"))
+    dtype = _lib.BF16 if os.environ.get("DTYPE", "bf16") == "bf16" else _lib.F32
+    tdt = torch.bfloat16 if dtype == _lib.BF16 else torch.float32
+    cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,17,18").split(",")]
+    reps = int(os.environ.get("REPS", "5"))
+    lib = _lib.load()
+    stream = torch.cuda.Stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    rows = []
+    for (h, cin, cout, taps) in SHAPES:
+        x = torch.randn(n, h, h, cin, device="cuda").to(tdt)
+        w = (torch.randn(cout, taps * cin, device="cuda") / (taps * cin) ** 0.5).to(tdt)
+        b = torch.randn(cout, device="cuda")
+        out = torch.empty(n, h, h, cout, device="cuda", dtype=tdt)
+        flop = 2.0 * n * h * h * cout * taps * cin
+        for cfg in cfgs:
+            def launch():
+                _lib.check(lib.ivid_conv2d(dtype, x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 0, 0,
+                                           n, h, h, cout, taps, cfg, None, sp), "conv")
+            launch()
+            torch.cuda.synchronize()
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            _lib.call("ivid_event_create", C.byref(e0)); _lib.call("ivid_event_create", C.byref(e1))
+            _lib.call("ivid_event_record", e0, sp)
+            for _ in range(reps):
+                launch()
+            _lib.call("ivid_event_record", e1, sp)
+            ms = C.c_float()
+            _lib.call("ivid_event_elapsed_ms", e0, e1, C.byref(ms))
+            t = ms.value / reps
+            rows.append(dict(h=h, cin=cin, cout=cout, taps=taps, cfg=cfg, ms=round(t, 4), tflops=round(flop / t / 1e9, 1)))
+            print(json.dumps(rows[-1]), flush=True)
+        del x, w, out
+    if os.environ.get("OUT"):
+        json.dump(rows, open(os.environ["OUT"], "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

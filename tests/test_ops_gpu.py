@@ -47,9 +47,16 @@ def run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg):
         out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
     else:
         out = torch.full((N, Cout, H, W), float("nan"), device="cuda", dtype=torch.float32)
+    want_stats = out_mode == 0 and (N * H * W) % 32 == 0
+    stats = torch.full((N * H * W // 32, Cout, 2), float("nan"), device="cuda") if want_stats else None
     L.call("ivid_conv2d", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(rd), res_mode,
-           out_mode, N, H, W, Cout, taps, tile_cfg, G.stream())
+           out_mode, N, H, W, Cout, taps, tile_cfg, L.ptr(stats), G.stream())
     torch.cuda.synchronize()
+    if want_stats:  # fused GroupNorm partials = per 32-pixel block sums of the STORED output
+        o = out.float().reshape(-1, 32, Cout)
+        ref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+        err = float((stats - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, f"fused GN statistics off by {err}"
     return G.from_nhwc(out) if out_mode == 0 else out.cpu()
 
 
@@ -67,6 +74,9 @@ CONV_CASES = [
     ("3x3_bigtile", 2, 32, 32, 128, 0, 512, 3, 1, 0, 2),
     ("3x3_bigtile_masks", 1, 24, 24, 64, 64, 320, 3, 0, 0, 2),
     ("3x3_64px_auto", 1, 64, 64, 256, 0, 256, 3, 0, 0, 0),
+    ("3x3_narrow_nchw_out4", 2, 32, 32, 128, 0, 4, 3, 0, 1, 3),
+    ("3x3_narrow_auto_c32", 1, 16, 16, 64, 0, 32, 3, 1, 0, 0),
+    ("3x3_tapmajor_legacy", 2, 16, 16, 128, 0, 128, 3, 0, 0, 17),
 ]
 
 
@@ -110,9 +120,9 @@ def test_conv2d_rejects_bad_arguments_without_aborting():
     L = G.lib()
     x = torch.zeros(1, 4, 4, 48, device="cuda")
     with pytest.raises(L.IvidHipError):
-        L.call("ivid_conv2d", 0, L.ptr(x), 48, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 9, 1, G.stream())
+        L.call("ivid_conv2d", 0, L.ptr(x), 48, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 9, 1, None, G.stream())
     with pytest.raises(L.IvidHipError):
-        L.call("ivid_conv2d", 0, L.ptr(x), 64, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 4, 1, G.stream())
+        L.call("ivid_conv2d", 0, L.ptr(x), 64, None, 0, L.ptr(x), None, L.ptr(x), None, 0, 0, 1, 4, 4, 64, 4, 1, None, G.stream())
 
 
 GN_CASES = [
@@ -171,6 +181,28 @@ def test_groupnorm_film_silu_resample(case, dtype):
     G.report(f"gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, y))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 1e-5, 5e-3), f"{name}: rel_l2 {e}"
+
+
+def test_gn_finalize_from_two_fused_partial_buffers_matches_single_buffer():
+    """Statistics of a skip concat arrive as two per-source buffers written by two conv epilogues."""
+    L = G.lib()
+    N, HW, C0, C1 = 2, 256, 128, 64
+    Cc, nch = C0 + C1, HW // 32
+    x = common.seeded_randn(3, N, HW, Cc)
+    blocks = x.reshape(N, nch, 32, Cc)
+    part = torch.stack([blocks.sum(2), (blocks * blocks).sum(2)], -1).cuda().contiguous()      # [N,nch,C,2]
+    p0, p1 = part[:, :, :C0].contiguous(), part[:, :, C0:].contiguous()
+    gamma, beta = (1 + 0.1 * common.seeded_randn(4, Cc)).cuda(), (0.1 * common.seeded_randn(5, Cc)).cuda()
+    ab1 = torch.empty(N, Cc, 2, device="cuda")
+    ab2 = torch.empty(N, Cc, 2, device="cuda")
+    L.call("ivid_gn_finalize", L.ptr(part), nch, N, Cc, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0, L.ptr(ab1), G.stream())
+    L.call("ivid_gn_finalize2", L.ptr(p0), C0, L.ptr(p1), C1, nch, N, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0,
+           L.ptr(ab2), G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ab1, ab2)
+    y = F.group_norm(x.permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5)
+    got = x.permute(0, 2, 1) * ab1[:, :, 0:1].cpu() + ab1[:, :, 1:2].cpu()
+    assert common.rel_l2(got, y) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
