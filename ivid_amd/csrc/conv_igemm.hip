@@ -45,7 +45,6 @@ struct ConvArgs {
   int M;
   int ntiles_n;
   int ntiles_total;
-  int korder;    // 0: tap-major K loop (tap outer, channel chunk inner); 1: chunk-major (chunk outer, tap inner)
   float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
 };
 
@@ -82,7 +81,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   const int tm = tile / p.ntiles_n, tn = tile - tm * p.ntiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay in SGPRs
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int HW = p.H * p.W;
   const int Ctot = p.C0 + p.C1;
@@ -91,20 +91,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   const size_t Ktot = (size_t)p.taps * Ctot;
 
   // ---- per-thread gather descriptors (K-step invariant) ----
-  int a_pix[A_IT], a_y[A_IT], a_x[A_IT], a_c[A_IT];
-  bool a_ok[A_IT];
+  // A piece i of this thread: tile row (pixel) and 16-byte column; its source address for K-step (tap, chunk) is
+  //   base{0,1}[i] + ((dy*W + dx)*Cs + chunk_offset) * sizeof(T)      (64-bit base + one wave-uniform 32-bit delta)
+  // or the zero page when the shifted pixel falls outside the image / the row is beyond M.  No branches, no 64-bit
+  // multiplies in the loop: everything the loop adds is uniform across the wave.
+  const char* a_base0[A_IT];
+  const char* a_base1[A_IT];
+  int a_y[A_IT], a_x[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int q = i * NT + tid;
     const int row = q >> 3, pos = q & 7;
-    a_c[i] = (pos ^ ((row >> 1) & 7)) * VE;
+    const int cpiece = (pos ^ ((row >> 1) & 7)) * 16;  // byte offset of the (swizzled) piece inside the 128-byte slab
     const int m = m0 + row;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     const int n = mm / HW, rem = mm - n * HW;
-    a_y[i] = rem / p.W;
-    a_x[i] = rem - a_y[i] * p.W;
-    a_pix[i] = mm;
+    const int y = rem / p.W;
+    a_y[i] = ok ? y : -0x40000000;  // out-of-range rows fail every bounds test
+    a_x[i] = rem - y * p.W;
+    a_base0[i] = p.src0 + (size_t)mm * p.C0 * sizeof(T) + cpiece;
+    a_base1[i] = p.src1 ? p.src1 + (size_t)mm * p.C1 * sizeof(T) + cpiece : p.zero;
   }
   const char* b_ptr[B_IT];
 #pragma unroll
@@ -116,13 +123,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     b_ptr[i] = (co < p.Cout) ? p.w + ((size_t)co * Ktot + c) * sizeof(T) : nullptr;
   }
 
+  // K-loop order: channel-chunk-major, taps inner — the 9 shifted re-reads of one 128-byte channel slab are back to
+  // back, so they hit in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the whole channel extent of
+  // the tile once per tap.  (The order must be a compile-time property: a runtime switch here made hipcc place an
+  // s_waitcnt vmcnt(0) between the A and the B batch of global_load_lds, serialising the load latency.)
   int ld_tap = 0, ld_ch = 0;  // K-step that the next issue() loads
   auto issue = [&](int stage) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + A_BYTES;
     const int cbase = ld_ch * BKE;
     const bool second = cbase >= p.C0;
-    const char* src = second ? p.src1 : p.src0;
     const int Cs = second ? p.C1 : p.C0;
     const int coff = second ? cbase - p.C0 : cbase;
     int dy = 0, dx = 0;
@@ -130,12 +140,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       dy = ld_tap / 3 - 1;
       dx = ld_tap - (dy + 1) * 3 - 1;
     }
+    const int delta = ((dy * p.W + dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-      const bool inb = a_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      const size_t e = (size_t)(a_pix[i] + dy * p.W + dx) * Cs + coff + a_c[i];
-      const char* g = inb ? src + e * sizeof(T) : p.zero;
+      const bool inb = (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+      const char* g = (second ? a_base1[i] : a_base0[i]) + delta;
+      g = inb ? g : p.zero;
       glds16(g, sA + (i * NT + wave * 64) * 16);
     }
     const size_t koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
@@ -144,19 +154,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
       glds16(g, sB + (i * NT + wave * 64) * 16);
     }
-    // K-loop order.  Chunk-major keeps the 9 shifted re-reads of one 128-byte channel slab back to back, so they hit
-    // in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the full channel extent of the tile per tap
-    // (256 px x C x 2 B x 32 resident tiles > 4 MiB L2).  The sum over K is order-independent up to fp32 rounding.
-    if (p.korder == 0) {
-      if (++ld_ch == chunks) {
-        ld_ch = 0;
-        ++ld_tap;
-      }
-    } else {
-      if (++ld_tap == p.taps) {
-        ld_tap = 0;
-        ++ld_ch;
-      }
+    if (++ld_tap == p.taps) {
+      ld_tap = 0;
+      ++ld_ch;
     }
   };
 
@@ -184,25 +184,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     b_sw[ni] = (row >> 1) & 7;
   }
 
+  auto load_frags = [&](const char* sA, const char* sB, int kk, vec_t* a, vec_t* b) {
+    const int piece = 2 * kk + fhalf;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
+  };
+
   issue(0);
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt0();
     __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
-    if (kt + 1 < nk) issue((kt + 1) & 1);
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + A_BYTES;
+    // the first fragments are requested BEFORE the next stage's 8 LDS-DMA loads are issued, so their LDS latency
+    // hides behind the address arithmetic instead of sitting in front of the first MFMA of the K-step
+    vec_t a[2][MI], b[2][NI];
+    load_frags(sA, sB, 0, a[0], b[0]);
+    if (kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      vec_t a[MI], b[NI];
-      const int piece = 2 * kk + fhalf;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
+      if (kk < 3) load_frags(sA, sB, kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(a[mi], b[ni], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni]);
     }
   }
 
@@ -367,8 +374,6 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
   if (stats && (out_mode != 0 || ((long long)N * H * W) % 32)) return ivid_set_error("conv: stats need NHWC output and M % 32 == 0", hipSuccess);
   a.stats = stats;
-  a.korder = (tile_cfg & 16) ? 0 : 1;   // bit 4 of tile_cfg selects the legacy tap-major order (A/B testing)
-  tile_cfg &= 15;
   hipStream_t s = (hipStream_t)stream;
   if (tile_cfg == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);

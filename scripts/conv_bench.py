@@ -28,7 +28,9 @@ def main():
     stream = torch.cuda.Stream()
     sp = C.c_void_p(stream.cuda_stream)
     rows = []
-    for (h, cin, cout, taps) in SHAPES:
+    only = os.environ.get("SHAPES_ONLY")
+    shapes = [SHAPES[int(i)] for i in only.split(",")] if only else SHAPES
+    for (h, cin, cout, taps) in shapes:
         x = torch.randn(n, h, h, cin, device="cuda").to(tdt)
         w = (torch.randn(cout, taps * cin, device="cuda") / (taps * cin) ** 0.5).to(tdt)
         b = torch.randn(cout, device="cuda")

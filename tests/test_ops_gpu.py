@@ -76,7 +76,6 @@ CONV_CASES = [
     ("3x3_64px_auto", 1, 64, 64, 256, 0, 256, 3, 0, 0, 0),
     ("3x3_narrow_nchw_out4", 2, 32, 32, 128, 0, 4, 3, 0, 1, 3),
     ("3x3_narrow_auto_c32", 1, 16, 16, 64, 0, 32, 3, 1, 0, 0),
-    ("3x3_tapmajor_legacy", 2, 16, 16, 128, 0, 128, 3, 0, 0, 17),
 ]
 
 
