@@ -64,7 +64,7 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool PF>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const ConvArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
+  static_assert(!PF || NT == 2 * BM, "prefetch mapping assumes two threads per tile row");
+  constexpr int PF_LDS = PF ? NT * 4 : 0;  // scratch landing zone of the L2-prefetch loads (never read)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -123,6 +125,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     b_ptr[i] = (co < p.Cout) ? p.w + ((size_t)co * Ktot + c) * sizeof(T) : nullptr;
   }
 
+  // L2 prefetch (PF): PMC showed the waves parked ~1/3 of the time in s_waitcnt/barrier although 90 % of the tile
+  // loads hit in L2 — every K-step waits for its SLOWEST load, i.e. for the compulsory HBM misses.  So each thread
+  // touches one 64-byte half of one tile row of the SAME tap `pf_dist` channel chunks ahead with a fire-and-forget
+  // 4-byte LDS-DMA into a scratch slab: by the time the real loads come, the lines sit in the XCD's L2.
+  const char* pf_base0 = nullptr;
+  const char* pf_base1 = nullptr;
+  int pf_y = -0x40000000, pf_x = 0;
+  if constexpr (PF) {
+    const int row = tid % BM, half = tid / BM;
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int n = m / HW, rem = m - n * HW;
+      pf_y = rem / p.W;
+      pf_x = rem - pf_y * p.W;
+    }
+    const int mm = m < p.M ? m : 0;
+    pf_base0 = p.src0 + (size_t)mm * p.C0 * sizeof(T) + half * 64;
+    pf_base1 = p.src1 ? p.src1 + (size_t)mm * p.C1 * sizeof(T) + half * 64 : p.zero;
+  }
+  const int pf_dist = p.taps == 9 ? 1 : 4;  // chunks ahead (>= ~8 K-steps of lead time)
+
   // K-loop order: channel-chunk-major, taps inner — the 9 shifted re-reads of one 128-byte channel slab are back to
   // back, so they hit in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the whole channel extent of
   // the tile once per tap.  (The order must be a compile-time property: a runtime switch here made hipcc place an
@@ -153,6 +176,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     for (int i = 0; i < B_IT; ++i) {
       const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
       glds16(g, sB + (i * NT + wave * 64) * 16);
+    }
+    if constexpr (PF) {
+      const int pc = cbase + pf_dist * BKE;          // first channel of the prefetched chunk
+      const bool same_src = second ? pc < Ctot : pc < p.C0;   // stay inside the current source tensor
+      const bool inb = (unsigned)(pf_y + dy) < (unsigned)p.H && (unsigned)(pf_x + dx) < (unsigned)p.W;
+      const char* g = (second ? pf_base1 : pf_base0) + delta + pf_dist * 128;
+      g = (inb && same_src) ? g : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + 2 * STAGE + wave * 256), 4, 0, 0);
     }
     if (++ld_tap == p.taps) {
       ld_tap = 0;
@@ -194,8 +225,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
 
   issue(0);
   for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt0();
-    __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
+    if constexpr (PF) {
+      // counted wait: everything but the newest VMEM op (the prefetch, issued last) has landed; raw barrier, because
+      // __syncthreads() would drain vmcnt to 0 and put the prefetch's HBM latency back on the critical path
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      wait_vmcnt0();
+      __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
+    }
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + A_BYTES;
     // the first fragments are requested BEFORE the next stage's 8 LDS-DMA loads are issued, so their LDS latency
@@ -214,6 +252,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   }
 
   // ---------------- epilogue ----------------
+  wait_vmcnt0();    // (PF) no LDS-DMA may still be in flight when the slabs are reused
   __syncthreads();  // all waves done with the operand stages; LDS is reused as per-wave slabs
   constexpr int LDC = WTN + 4;  // floats per slab row (pad keeps the two half-waves on different banks)
   float* slab = (float*)smem + wave * (32 * LDC);
@@ -330,17 +369,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool PF>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   ConvArgs a = a0;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
-  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  constexpr int SMEM = ((2 * STAGE > EPI) ? 2 * STAGE : EPI) + (PF ? NT * 4 : 0);
   const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
   a.ntiles_n = nt;
   a.ntiles_total = mt * nt;
-  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -375,17 +414,19 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (stats && (out_mode != 0 || ((long long)N * H * W) % 32)) return ivid_set_error("conv: stats need NHWC output and M % 32 == 0", hipSuccess);
   a.stats = stats;
   hipStream_t s = (hipStream_t)stream;
-  if (tile_cfg == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
+  if ((tile_cfg & 7) == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
-    tile_cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1);
+    tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1));
   }
-  if (dtype == IVID_BF16) {
-    if (tile_cfg == 2) return launch_conv<__bf16, 256, 256, 2, 4>(a, s);
-    if (tile_cfg == 3) return launch_conv<__bf16, 128, 32, 4, 1>(a, s);
-    return launch_conv<__bf16, 128, 128, 2, 2>(a, s);
-  } else {
-    if (tile_cfg == 2) return launch_conv<float, 256, 256, 2, 4>(a, s);
-    if (tile_cfg == 3) return launch_conv<float, 128, 32, 4, 1>(a, s);
-    return launch_conv<float, 128, 128, 2, 2>(a, s);
-  }
+  const bool pf = !(tile_cfg & 8);   // bit 3 of tile_cfg disables the L2 prefetch (tuning / A-B only)
+  tile_cfg &= 7;
+#define IVID_CONV_DISPATCH(TT)                                                        \
+  do {                                                                                \
+    if (tile_cfg == 2) return pf ? launch_conv<TT, 256, 256, 2, 4, true>(a, s) : launch_conv<TT, 256, 256, 2, 4, false>(a, s); \
+    if (tile_cfg == 3) return pf ? launch_conv<TT, 128, 32, 4, 1, true>(a, s) : launch_conv<TT, 128, 32, 4, 1, false>(a, s);   \
+    return pf ? launch_conv<TT, 128, 128, 2, 2, true>(a, s) : launch_conv<TT, 128, 128, 2, 2, false>(a, s);                    \
+  } while (0)
+  if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);
+  IVID_CONV_DISPATCH(float);
+#undef IVID_CONV_DISPATCH
 }

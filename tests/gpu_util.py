@@ -12,12 +12,20 @@ _report = {}
 
 
 def report(key, **vals):
-    _report[key] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in vals.items()}
+    def plain(v):
+        try:
+            return float(v)
+        except (TypeError, ValueError):
+            return str(v)
+    _report[key] = {k: plain(v) for k, v in vals.items()}
     try:
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
         old = {}
         if os.path.exists(REPORT):
-            old = json.load(open(REPORT))
+            try:
+                old = json.load(open(REPORT))
+            except Exception:
+                old = {}
         old.update(_report)
         json.dump(old, open(REPORT, "w"), indent=1, sort_keys=True)
     except Exception:
