@@ -418,7 +418,7 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
     tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1));
   }
-  const bool pf = !(tile_cfg & 8);   // bit 3 of tile_cfg disables the L2 prefetch (tuning / A-B only)
+  const bool pf = (tile_cfg & 8) != 0;   // bit 3 of tile_cfg ENABLES the L2 prefetch (measured slower: off by default)
   tile_cfg &= 7;
 #define IVID_CONV_DISPATCH(TT)                                                        \
   do {                                                                                \

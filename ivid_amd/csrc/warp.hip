@@ -20,6 +20,10 @@
 #include "common.h"
 #include "internal.h"
 
+// The mesh / raster arithmetic mirrors numpy (separately rounded float32 / float64 operations): no FMA contraction,
+// otherwise a 1-ulp change of a depth shows up as ~1e-5 in the Sobel normals (differences of neighbouring points).
+#pragma clang fp contract(off)
+
 namespace {
 
 struct MeshParams {
