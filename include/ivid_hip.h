@@ -56,6 +56,16 @@ int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, c
                 void* out, const void* res, int res_mode, int out_mode, int N, int H, int W, int Cout, int taps,
                 int tile_cfg, float* stats, void* stream);
 
+/* ---- fused GroupNorm-apply (+FiLM) + SiLU [+ nearest x2 upsample] + Conv2d 3x3 (ResBlock2d in_layers / out_layers,
+ *      adm.py:157-161,177-183,203-208,214-219) for W % 32 == 0, H % 8 == 0 ----
+ * out = bias + conv3x3( pad0( up?( silu( cat(src0,src1) * a + b ) ) ) ) (+ residual), with a,b = ab[n][c][0..1] from
+ * ivid_gn_finalize{,2}.  The activated tensor never exists in HBM: the (8+2)x(32+2) pixel halo of each tile is
+ * transformed once while it is staged into LDS.  up = 1: src is [N,H/2,W/2,C] (Upsample2d inside an `up` ResBlock).
+ * res_mode: 0 none, 1 same size, 2 nearest-x2-upsampled residual [N,H/2,W/2,Cout].  stats: as ivid_conv2d. */
+int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                    const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
+                    int Cout, float* stats, void* stream);
+
 /* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
  * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).
  *   partial: fp32 [N][nchunks][C0+C1][2]; nchunks = ivid_gn_num_chunks(H*W). */

@@ -127,6 +127,7 @@ class UNetPlan:
         self.spec, self.w, self.device = spec, weights, device
         self.debug = debug      # eager-only: snapshot every op's output (NCHW fp32) into self.taps
         self.fuse_stats = os.environ.get("IVID_NO_FUSED_STATS", "0") != "1"   # GN partials from conv epilogues
+        self.fuse_conv = os.environ.get("IVID_NO_FUSED_CONV", "0") != "1"     # GN-apply+SiLU inside the 3x3 conv (W >= 32)
         self.taps = {}
         self.dtype = weights.dtype
         self.esz = 4 if self.dtype == _lib.F32 else 2
@@ -190,18 +191,16 @@ class UNetPlan:
         self._conv(_lib.F32, x.data_ptr(), k, None, 0, wname, out.data_ptr(), res.data_ptr() if res is not None else None,
                    1 if res is not None else 0, 0, self.n, 1, 1, cout, 1)
 
-    def _gn(self, x0: _Act, x1, gname, film_off, resample, act):
-        """GroupNorm(+FiLM)(+SiLU)(+resample) of cat(x0,x1) -> new activation."""
+    def _gn_coeffs(self, x0: _Act, x1, gname, film_off):
+        """GroupNorm statistics of cat(x0,x1) folded with gamma/beta (+FiLM) -> per-(image, channel) (a, b) buffer."""
         n, side = x0.n, x0.side
         c0, c1 = x0.c, (x1.c if x1 is not None else 0)
         c = c0 + c1
         hw = side * side
         ab = self.arena.get(n * c * 2 * 4)
-        p1 = x1.ptr if x1 is not None else None
         film = self.embproj.data_ptr() if film_off is not None else None
         fo = film_off if film_off is not None else 0
         gw, gb = self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr()
-        partial = None
         if x0.stats is not None and (x1 is None or x1.stats is not None):
             # statistics came for free from the producers' epilogues (one buffer per concat source)
             self._rec("ivid_gn_finalize2", x0.stats.data_ptr(), c0, x1.stats.data_ptr() if x1 is not None else None, c1,
@@ -209,29 +208,53 @@ class UNetPlan:
         else:
             nch = self.lib.ivid_gn_num_chunks(hw)
             partial = self.arena.get(n * nch * c * 2 * 4)
-            self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, p1, c1, n, hw, partial.data_ptr())
+            self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, n, hw,
+                      partial.data_ptr())
             self._rec("ivid_gn_finalize", partial.data_ptr(), nch, n, c, hw, self.spec.num_groups, 1e-5, gw, gb, film,
                       self.spec.emb_total, fo, ab.data_ptr())
-        so = {0: side, 1: side * 2, 2: side // 2}[resample]
-        y = self._new(n, so, c)
-        self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, p1, c1, ab.data_ptr(), y.ptr, n, side, side, resample, act)
-        if partial is not None:
             self.arena.put(partial)
+        return ab
+
+    def _gn(self, x0: _Act, x1, gname, film_off, resample, act):
+        """GroupNorm(+FiLM)(+SiLU)(+resample) of cat(x0,x1) materialised as a new activation (unfused path)."""
+        n, side = x0.n, x0.side
+        c0, c1 = x0.c, (x1.c if x1 is not None else 0)
+        ab = self._gn_coeffs(x0, x1, gname, film_off)
+        so = {0: side, 1: side * 2, 2: side // 2}[resample]
+        y = self._new(n, so, c0 + c1)
+        self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, ab.data_ptr(), y.ptr, n,
+                  side, side, resample, act)
         self.arena.put(ab)
         return y
+
+    def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode):
+        """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip)."""
+        self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
+                  x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
+                  self.w[wname + ".bias"].data_ptr(), out.ptr, res_ptr, res_mode, out.n, out.side, out.side, out.c,
+                  out.stats.data_ptr() if out.stats is not None else None)
 
     # ---- ops ----
     def _res(self, op: Res, x: _Act, skip):
         n = x.n
         resample = {"same": 0, "up": 1, "down": 2}[op.mode]
-        act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
         so = op.res_out
+        fused = self.fuse_conv and op.mode != "down" and so % 32 == 0
         h1 = self._new(n, so, op.cout, stats=True)
-        self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
-                   op.cout, 9, stats=h1.stats)
-        self._free(act1)
-        act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
-        self._free(h1)
+        if fused:
+            ab1 = self._gn_coeffs(x, skip, op.prefix + ".in_layers.0", None)
+            self._conv3_gn(x, skip, ab1, op.mode == "up", op.prefix + ".in_layers.2", h1, None, 0)
+            self.arena.put(ab1)
+        else:
+            act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
+            self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
+                       op.cout, 9, stats=h1.stats)
+            self._free(act1)
+        if fused:
+            ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off)
+        else:
+            act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
+            self._free(h1)
         out = self._new(n, so, op.cout, stats=True)
         if op.has_skip_conv:
             assert op.mode == "same"
@@ -243,9 +266,14 @@ class UNetPlan:
             assert skip is None
             r = None
             res_ptr, res_mode = x.ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
-        self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
-                   n, so, so, op.cout, 9, stats=out.stats)
-        self._free(act2)
+        if fused:
+            self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode)
+            self.arena.put(ab2)
+            self._free(h1)
+        else:
+            self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
+                       n, so, so, op.cout, 9, stats=out.stats)
+            self._free(act2)
         if r is not None:
             self._free(r)
         return out

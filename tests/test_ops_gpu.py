@@ -105,6 +105,69 @@ def test_conv2d(case, dtype):
     assert e < G.tol(dtype), f"{name}: rel_l2 {e}"
 
 
+FUSED_CASES = [
+    # name, N, H, W, C0, C1, Cout, up, res_mode
+    ("same_c64", 2, 32, 32, 64, 0, 64, 0, 0),
+    ("concat_res", 2, 32, 32, 128, 64, 128, 0, 1),
+    ("up_res_up", 2, 32, 32, 64, 0, 64, 1, 2),
+    ("wide_2ntiles", 1, 16, 64, 64, 0, 512, 0, 1),
+    ("tall_cout320", 1, 40, 32, 128, 0, 320, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_conv3x3_gn_fused(case, dtype):
+    """Fused GN-apply + SiLU (+ x2 nearest upsample) + conv3x3 vs the unfused torch composition (adm.py:203-219)."""
+    name, N, H, W, C0, C1, Cout, up, res_mode = case
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    Cc = C0 + C1
+    x0 = common.seeded_randn(s, N, C0, Hs, Ws)
+    x1 = common.seeded_randn(s + 1, N, C1, Hs, Ws) if C1 else None
+    a = 0.5 + 0.5 * torch.rand(N, Cc, generator=torch.Generator().manual_seed(s))
+    b = 0.3 * common.seeded_randn(s + 2, N, Cc)
+    w = common.seeded_randn(s + 3, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    bias = common.seeded_randn(s + 4, Cout) * 0.1
+    res = None
+    if res_mode == 1:
+        res = common.seeded_randn(s + 5, N, Cout, H, W)
+    elif res_mode == 2:
+        res = common.seeded_randn(s + 5, N, Cout, H // 2, W // 2)
+    # reference
+    x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    act = F.silu(x * a[:, :, None, None] + b[:, :, None, None])
+    if up:
+        act = F.interpolate(act, scale_factor=2, mode="nearest")
+    act = G.rounded(act, dtype)                      # the kernel stores the activated halo in the compute dtype
+    ref = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1)
+    if res_mode == 1:
+        ref = ref + G.rounded(res, dtype).double()
+    elif res_mode == 2:
+        ref = ref + F.interpolate(G.rounded(res, dtype).double(), scale_factor=2, mode="nearest")
+    ref = ref.float()
+    d0 = G.to_nhwc(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    bd = bias.cuda()
+    rd = G.to_nhwc(res, dtype) if res is not None else None
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    stats = torch.full((N * H * W // 32, Cout, 2), float("nan"), device="cuda")
+    L.call("ivid_conv3x3_gn", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), up, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(rd),
+           res_mode, N, H, W, Cout, L.ptr(stats), G.stream())
+    torch.cuda.synchronize()
+    got = G.from_nhwc(out)
+    e = common.rel_l2(got, ref)
+    G.report(f"conv3x3_gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
+    o = out.float().reshape(-1, 32, Cout)
+    sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
+
+
 def test_conv2d_is_transpose_detecting_identity_weights():
     # A = asymmetric ramp, W = identity 1x1: out must equal in exactly (catches swapped C/D row/col maps)
     N, H, W, Cc = 1, 16, 16, 128
