@@ -38,6 +38,12 @@ def conv_flops(args):
     return 2.0 * n * h * w * cout * taps * (c0 + c1), dtype
 
 
+def fused_flops(args):
+    """Algorithmic FLOPs of one ivid_conv3x3_gn launch (2 x MACs; the GroupNorm/SiLU prologue counts 0)."""
+    (_dtype, _s0, c0, _s1, c1, _ab, _up, _w, _b, _o, _r, _rm, n, h, w, cout, _st) = args
+    return 2.0 * n * h * w * cout * 9 * (c0 + c1)
+
+
 def attn_flops(args):
     (_dtype, _q, _o, n, t, heads) = args
     return 2.0 * (2.0 * heads * t * t * 64) * n
@@ -149,13 +155,18 @@ def main():
                 fl, dt_ = conv_flops(args)
                 if dt_ == (1 if a.precision == "bf16" else 0):
                     f["flop"] += fl
+            elif name == "ivid_conv3x3_gn":
+                f["flop"] += fused_flops(args)
             elif name == "ivid_attention":
                 f["flop"] += attn_flops(args)
         total_ms = sum(f["ms"] for f in fam.values())
-        conv = fam["ivid_conv2d"]
+        conv = dict(fam["ivid_conv2d"])
+        if "ivid_conv3x3_gn" in fam:  # the two MFMA convolution kernels together = 97 % of the model's FLOPs
+            for k in ("ms", "n", "flop"):
+                conv[k] += fam["ivid_conv3x3_gn"][k]
         ach = conv["flop"] / (conv["ms"] * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "conv_igemm_kernel (all %d launches of one batch-%d forward)" % (conv["n"], plan.n),
+            "kernel": "conv3x3_fused_kernel + conv_igemm_kernel (all %d convolution launches of one batch-%d forward)" % (conv["n"], plan.n),
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": None,
             "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
@@ -170,6 +181,10 @@ def main():
                     fl, _ = conv_flops(args)
                     rows.append(dict(n=args[11], h=args[12], cin=args[2] + args[4], cout=args[14], taps=args[15],
                                      res=args[9], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+                elif name == "ivid_conv3x3_gn":
+                    fl = fused_flops(args)
+                    rows.append(dict(fused=1, n=args[12], h=args[13], cin=args[2] + args[4], cout=args[15], taps=9, up=args[6],
+                                     res=args[11], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
                 elif name in ("ivid_gn_apply", "ivid_gn_partial", "ivid_attention"):
                     rows.append(dict(op=name, args=[a for a in args if isinstance(a, int) and a < (1 << 32)], ms=round(ms, 4)))
             with open(os.environ["IVID_BENCH_LAYERS"], "w") as f:

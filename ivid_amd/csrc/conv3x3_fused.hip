@@ -138,9 +138,11 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       glds16(g, sB + (i * NT + wave * 64) * 16);
     }
   };
-  // GroupNorm coefficients of chunk ch -> LDS (512 B by LDS-DMA from lanes 0..31 of wave 0): kept out of the VGPRs
+  // GroupNorm coefficients of chunk ch -> LDS by LDS-DMA from wave 0 (BKE channels x (a,b) x 4 B = 512 B for bf16,
+  // 256 B for fp32: exactly BKE/2 lanes x 16 B, never past the end of the coefficient buffer): kept out of the VGPRs
   auto issue_ab = [&](int ch) {
-    if (wave == 0 && lane < 32) glds16((const char*)(abn + (size_t)ch * BKE * 2) + lane * 16, sAB0 + (ch & 1) * AB_BYTES);
+    if (wave == 0 && lane < BKE / 2)
+      glds16((const char*)(abn + (size_t)ch * BKE * 2) + lane * 16, sAB0 + (ch & 1) * AB_BYTES);
   };
 
   // raw load of halo piece j of channel chunk ch (zero page for padding / idle lanes)
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   __syncthreads();
   {
     const ChunkSrc cs0 = chunk_src(0);
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < PIECES; ++j) {
       const vec_t raw = load_piece(j, cs0);
       store_piece(j, raw, 0, sA0);

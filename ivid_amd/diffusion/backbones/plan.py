@@ -353,11 +353,17 @@ class UNetPlan:
     # ---- execution ----
     def _enqueue(self, stream):
         sp = C.c_void_p(stream)
+        trace = os.environ.get("IVID_TRACE") == "1"
         for fn, name, args in self.launches:
             if fn is None:
                 args()
                 continue
-            st = fn(*args, sp)
+            if trace:  # debugging aid: last line printed before a fault names the launch
+                print("[ivid] launch", name, [a for a in args if not isinstance(a, int) or a < (1 << 32)], flush=True)
+                st = fn(*args, sp)
+                torch.cuda.synchronize(self.device)
+            else:
+                st = fn(*args, sp)
             if st != 0:
                 _lib.check(st, name)
 
