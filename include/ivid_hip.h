@@ -49,19 +49,23 @@ int ivid_event_destroy(void* ev);
  *   out_mode  : 0 NHWC dtype [N,H,W,Cout]; 1 fp32 NCHW [N,Cout,H,W] (final conv, adm.py:566)
  *   tile_cfg  : 0 auto, 1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 3 = 128x32 tile (narrow Cout);
  *               +8 = also prefetch the next channel chunk into L2 (experiment: measured 5-15 % slower, off by default)
- *   stats     : NULL, or fp32 [N*H*W/32][Cout][2]: per 32-pixel row block and output channel, sum and sum of squares
- *               of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this epilogue
- *               (same layout as ivid_gn_partial with H*W/32 chunks per image) */
+ *   stats     : NULL, or fp32 [N*H*W/blk][Cout][2]: per block of blk consecutive pixels and output channel, sum and sum
+ *               of squares of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this
+ *               epilogue (same layout as ivid_gn_partial with H*W/blk chunks per image); blk = one wave's rows =
+ *               ivid_conv2d_stats_block(...) (64 / 128 / 32 for tile_cfg 1 / 2 / 3), H*W % blk must be 0 */
 int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias,
                 void* out, const void* res, int res_mode, int out_mode, int N, int H, int W, int Cout, int taps,
                 int tile_cfg, float* stats, void* stream);
+
+int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg);
 
 /* ---- fused GroupNorm-apply (+FiLM) + SiLU [+ nearest x2 upsample] + Conv2d 3x3 (ResBlock2d in_layers / out_layers,
  *      adm.py:157-161,177-183,203-208,214-219) for W % 32 == 0, H % 8 == 0 ----
  * out = bias + conv3x3( pad0( up?( silu( cat(src0,src1) * a + b ) ) ) ) (+ residual), with a,b = ab[n][c][0..1] from
  * ivid_gn_finalize{,2}.  The activated tensor never exists in HBM: the (8+2)x(32+2) pixel halo of each tile is
  * transformed once while it is staged into LDS.  up = 1: src is [N,H/2,W/2,C] (Upsample2d inside an `up` ResBlock).
- * res_mode: 0 none, 1 same size, 2 nearest-x2-upsampled residual [N,H/2,W/2,Cout].  stats: as ivid_conv2d. */
+ * res_mode: 0 none, 1 same size, 2 nearest-x2-upsampled residual [N,H/2,W/2,Cout].
+ * stats: as ivid_conv2d with 128-pixel blocks (4 image rows x 32 columns; H*W/128 blocks per image). */
 int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                     const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
                     int Cout, float* stats, void* stream);
@@ -80,8 +84,8 @@ int ivid_gn_finalize(const float* partial, int nchunks, int N, int C, int HW, in
                      const float* gamma, const float* beta, const float* film, int film_stride, int film_off,
                      float* ab, void* stream);
 /* Same, with the statistics of a skip concat kept as two separate partial buffers (one per source tensor, as the
- * producing convolutions' epilogues wrote them): partial0 [N][nchunks][C0][2], partial1 [N][nchunks][C1][2]. */
-int ivid_gn_finalize2(const float* partial0, int C0, const float* partial1, int C1, int nchunks, int N, int HW,
+ * producing convolutions' epilogues wrote them): partial0 [N][nchunks0][C0][2], partial1 [N][nchunks1][C1][2]. */
+int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, const float* partial1, int C1, int nchunks1, int N, int HW,
                       int groups, float eps, const float* gamma, const float* beta, const float* film,
                       int film_stride, int film_off, float* ab, void* stream);
 /* Step 3: out = act(x*a+b) with optional resampling folded in (adm.py:203-208):

@@ -39,11 +39,12 @@ SIGNATURES = {
     "ivid_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
     "ivid_event_destroy": (i32, [vp]),
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
     "ivid_conv3x3_gn": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_gn_num_chunks": (i32, [i32]),
     "ivid_gn_partial": (i32, [i32, vp, i32, vp, i32, i32, i32, vp, vp]),
     "ivid_gn_finalize": (i32, [vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, i32, i32, vp, vp]),
-    "ivid_gn_finalize2": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, i32, i32, vp, vp]),
+    "ivid_gn_finalize2": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, i32, i32, vp, vp]),
     "ivid_gn_apply": (i32, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ivid_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "ivid_embed_inputs": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp]),

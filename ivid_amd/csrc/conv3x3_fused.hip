@@ -215,9 +215,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         wait_vmcnt0();
         __syncthreads();  // weights of this step landed; halo writes of earlier steps visible; previous reads finished
         const char* sB = sB0 + (kstep & 1) * B_BYTES;
-        // ---- consume the halo piece issued three taps ago (landed: everything in flight was drained above) ----
-        if (more && g >= 1) store_piece(3 * (g - 1) + t, raw[t], ch + 1, sAn);
-        // ---- first fragments of this step ----
+        // ---- first fragments of this step (requested first: their LDS latency hides behind the transform below) ----
         const int tapoff = (g - 1) * HW_ + (t - 1);
         vec_t a[MI], b[NI];
         int a_addr[MI];
@@ -233,6 +231,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off0 + ni * 4096 + ((fhalf ^ b_sw0) << 4));
+        // ---- consume the halo piece issued three taps ago (landed: everything in flight was drained above) ----
+        if (more && g >= 1) store_piece(3 * (g - 1) + t, raw[t], ch + 1, sAn);
         // ---- issue: weights of the next K-step, one raw halo piece of the next chunk ----
         {
           const bool last = (g == 2) && (t == 2);
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   constexpr int LDC = WTN + 4;
   float* slab = (float*)smem + wave * (32 * LDC);
   const int Cout = p.Cout;
+  float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's 128 pixels (fused gn_partial)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -285,9 +286,10 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     const int nbase = n0 + wn * WTN;
     constexpr int LPR = WTN / VE, RPP = 64 / LPR;
     const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-    float st_s[VE], st_q[VE];
+    if (mi == 0) {
 #pragma unroll
-    for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+      for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+    }
 #pragma unroll
     for (int ps = 0; ps < 32 / RPP; ++ps) {
       const int row = ps * RPP + lr;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
       }
     }
-    if (p.stats) {
+    if (p.stats && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -340,7 +342,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       }
       const int n = nbase + lc;
       if (lr == 0 && n < Cout) {
-        float* sp = p.stats + ((mbase >> 5) * Cout + n) * 2;
+        // block id inside the image: (pair of 4-row bands) x (32-pixel columns); any partition of the image works
+        const size_t blk = (size_t)img * (p.H / 4) * p.tiles_x + (size_t)(ty * 2 + wm) * p.tiles_x + tx;
+        float* sp = p.stats + (blk * Cout + n) * 2;
 #pragma unroll
         for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
       }

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   constexpr int LDC = WTN + 4;  // floats per slab row (pad keeps the two half-waves on different banks)
   float* slab = (float*)smem + wave * (32 * LDC);
   const int Cout = p.Cout;
+  float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's WTM pixels (fused gn_partial)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -273,9 +274,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       constexpr int LPR = WTN / VE;   // lanes per slab row
       constexpr int RPP = 64 / LPR;   // rows per pass
       const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-      float st_s[VE], st_q[VE];       // GroupNorm partial statistics of this 32-row block (fused gn_partial)
+      if (mi == 0) {
 #pragma unroll
-      for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+        for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+      }
 #pragma unroll
       for (int ps = 0; ps < 32 / RPP; ++ps) {
         const int row = ps * RPP + lr;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
         }
       }
-      if (p.stats) {
+      if (p.stats && mi == MI - 1) {  // one partial per wave: WTM consecutive pixels
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -346,8 +348,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
         }
         const int n = nbase + lc;
-        if (lr == 0 && mbase < p.M && n < Cout) {
-          float* sp = p.stats + ((size_t)(mbase >> 5) * Cout + n) * 2;
+        const int wbase = m0 + wm * WTM;  // first pixel of this wave's block
+        if (lr == 0 && wbase < p.M && n < Cout) {
+          float* sp = p.stats + ((size_t)(wbase / WTM) * Cout + n) * 2;
 #pragma unroll
           for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
         }
@@ -411,12 +414,15 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (!a.zero) return -1;
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
-  if (stats && (out_mode != 0 || ((long long)N * H * W) % 32)) return ivid_set_error("conv: stats need NHWC output and M % 32 == 0", hipSuccess);
   a.stats = stats;
   hipStream_t s = (hipStream_t)stream;
   if ((tile_cfg & 7) == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
     tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1));
+  }
+  if (stats) {  // one partial per wave = per WTM pixels; a block must not straddle two images
+    const int gran = (tile_cfg & 7) == 2 ? 128 : ((tile_cfg & 7) == 3 ? 32 : 64);
+    if (out_mode != 0 || (H * W) % gran) return ivid_set_error("conv: stats need NHWC output and H*W % block == 0", hipSuccess);
   }
   const bool pf = (tile_cfg & 8) != 0;   // bit 3 of tile_cfg ENABLES the L2 prefetch (measured slower: off by default)
   tile_cfg &= 7;
@@ -429,4 +435,15 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);
   IVID_CONV_DISPATCH(float);
 #undef IVID_CONV_DISPATCH
+}
+
+// Pixels per GroupNorm-statistics block that ivid_conv2d will write for this problem (depends on the tile it picks).
+extern "C" int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg) {
+  int cfg = tile_cfg & 7;
+  if (cfg == 0) {
+    const long long M = (long long)N * H * W;
+    const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
+    cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1);
+  }
+  return cfg == 2 ? 128 : (cfg == 3 ? 32 : 64);
 }

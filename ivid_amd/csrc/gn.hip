@@ -91,7 +91,8 @@ __global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restric
 }
 
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int C0,
-                                                         const float* __restrict__ partial1, int nchunks, int C,
+                                                         const float* __restrict__ partial1, int nchunks,
+                                                         int nchunks1, int C,
                                                          int HW, int groups, float eps,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
@@ -100,12 +101,21 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int cpg = C / groups;
   const int C1 = C - C0;
+  // the two concat sources may come with different block counts (their producers used different tiles)
   const float* pp0 = partial + (size_t)n * nchunks * C0 * 2;
-  const float* pp1 = partial1 ? partial1 + (size_t)n * nchunks * C1 * 2 : nullptr;
+  const float* pp1 = partial1 ? partial1 + (size_t)n * nchunks1 * C1 * 2 : nullptr;
+  const int nmax = nchunks > nchunks1 ? nchunks : nchunks1;
   double s = 0.0, ss = 0.0;
-  for (int idx = t; idx < nchunks * cpg; idx += 64) {
+  for (int idx = t; idx < nmax * cpg; idx += 64) {
     const int ch = idx / cpg, c = g * cpg + (idx - ch * cpg);
-    const float* q = c < C0 ? pp0 + ((size_t)ch * C0 + c) * 2 : pp1 + ((size_t)ch * C1 + (c - C0)) * 2;
+    const float* q;
+    if (c < C0) {
+      if (ch >= nchunks) continue;
+      q = pp0 + ((size_t)ch * C0 + c) * 2;
+    } else {
+      if (ch >= nchunks1) continue;
+      q = pp1 + ((size_t)ch * C1 + (c - C0)) * 2;
+    }
     s += (double)q[0];
     ss += (double)q[1];
   }
@@ -241,18 +251,19 @@ extern "C" int ivid_gn_finalize(const float* partial, int nchunks, int N, int C,
                                 int film_off, float* ab, void* stream) {
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize: C must be divisible by groups", hipSuccess);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial, C, nullptr, nchunks,
-                     C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
+                     0, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize");
 }
 
-extern "C" int ivid_gn_finalize2(const float* partial0, int C0, const float* partial1, int C1, int nchunks, int N, int HW,
+extern "C" int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, const float* partial1, int C1, int nchunks1,
+                                 int N, int HW,
                                  int groups, float eps, const float* gamma, const float* beta, const float* film,
                                  int film_stride, int film_off, float* ab, void* stream) {
   const int C = C0 + C1;
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize2: C must be divisible by groups", hipSuccess);
   if (C1 > 0 && !partial1) return ivid_set_error("gn_finalize2: partial1 missing", hipSuccess);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks,
-                     C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks0,
+                     nchunks1, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize2");
 }
 

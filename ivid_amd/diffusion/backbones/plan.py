@@ -112,10 +112,11 @@ class _Arena:
 class _Act:
     """An NHWC activation living in an arena buffer (+ optionally the GroupNorm partial statistics its producing
     convolution wrote: fp32 [n*side*side/32][c][2])."""
-    __slots__ = ("buf", "n", "side", "c", "stats")
+    __slots__ = ("buf", "n", "side", "c", "stats", "stats_blk")
 
     def __init__(self, buf, n, side, c, stats=None):
         self.buf, self.n, self.side, self.c, self.stats = buf, n, side, c, stats
+        self.stats_blk = 32   # pixels per statistics block, set by the producing launch
 
     @property
     def ptr(self):
@@ -182,7 +183,10 @@ class UNetPlan:
             self.arena.put(act.stats)
 
     def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
-              stats=None):
+              stats=None, out_act=None):
+        if out_act is not None and out_act.stats is not None:
+            stats = out_act.stats
+            out_act.stats_blk = self.lib.ivid_conv2d_stats_block(n, h, w, cout, self.tile_cfg)
         self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
                   self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
                   self.tile_cfg, stats.data_ptr() if stats is not None else None)
@@ -203,8 +207,9 @@ class UNetPlan:
         gw, gb = self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr()
         if x0.stats is not None and (x1 is None or x1.stats is not None):
             # statistics came for free from the producers' epilogues (one buffer per concat source)
-            self._rec("ivid_gn_finalize2", x0.stats.data_ptr(), c0, x1.stats.data_ptr() if x1 is not None else None, c1,
-                      hw // 32, n, hw, self.spec.num_groups, 1e-5, gw, gb, film, self.spec.emb_total, fo, ab.data_ptr())
+            self._rec("ivid_gn_finalize2", x0.stats.data_ptr(), c0, hw // x0.stats_blk,
+                      x1.stats.data_ptr() if x1 is not None else None, c1, hw // x1.stats_blk if x1 is not None else 0,
+                      n, hw, self.spec.num_groups, 1e-5, gw, gb, film, self.spec.emb_total, fo, ab.data_ptr())
         else:
             nch = self.lib.ivid_gn_num_chunks(hw)
             partial = self.arena.get(n * nch * c * 2 * 4)
@@ -229,6 +234,7 @@ class UNetPlan:
 
     def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode):
         """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip)."""
+        out.stats_blk = 128
         self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
                   x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
                   self.w[wname + ".bias"].data_ptr(), out.ptr, res_ptr, res_mode, out.n, out.side, out.side, out.c,
@@ -248,7 +254,7 @@ class UNetPlan:
         else:
             act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
             self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
-                       op.cout, 9, stats=h1.stats)
+                       op.cout, 9, out_act=h1)
             self._free(act1)
         if fused:
             ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off)
@@ -272,7 +278,7 @@ class UNetPlan:
             self._free(h1)
         else:
             self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
-                       n, so, so, op.cout, 9, stats=out.stats)
+                       n, so, so, op.cout, 9, out_act=out)
             self._free(act2)
         if r is not None:
             self._free(r)
@@ -289,7 +295,7 @@ class UNetPlan:
         self._free(qkv)
         out = self._new(n, side, c, stats=True)
         self._conv(self.dtype, a.ptr, c, None, 0, op.prefix + ".proj_out", out.ptr, x.ptr, 1, 0, n, side, side, c, 1,
-                   stats=out.stats)
+                   out_act=out)
         self._free(a)
         return out
 
@@ -317,7 +323,7 @@ class UNetPlan:
                   xin.ptr)
         h = self._new(n, S, sp.stem_out, stats=True)
         self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9,
-                   stats=h.stats)
+                   out_act=h)
         self._free(xin)
         self._tap("stem", h)
         stash = [h]

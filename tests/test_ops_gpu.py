@@ -47,13 +47,14 @@ def run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg):
         out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
     else:
         out = torch.full((N, Cout, H, W), float("nan"), device="cuda", dtype=torch.float32)
-    want_stats = out_mode == 0 and (N * H * W) % 32 == 0
-    stats = torch.full((N * H * W // 32, Cout, 2), float("nan"), device="cuda") if want_stats else None
+    blk = L.load().ivid_conv2d_stats_block(N, H, W, Cout, tile_cfg)
+    want_stats = out_mode == 0 and (H * W) % blk == 0
+    stats = torch.full((N * H * W // blk, Cout, 2), float("nan"), device="cuda") if want_stats else None
     L.call("ivid_conv2d", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(rd), res_mode,
            out_mode, N, H, W, Cout, taps, tile_cfg, L.ptr(stats), G.stream())
     torch.cuda.synchronize()
     if want_stats:  # fused GroupNorm partials = per 32-pixel block sums of the STORED output
-        o = out.float().reshape(-1, 32, Cout)
+        o = out.float().reshape(-1, blk, Cout)
         ref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
         err = float((stats - ref).abs().max() / ref.abs().max())
         assert err < 1e-5, f"fused GN statistics off by {err}"
@@ -154,7 +155,7 @@ def test_conv3x3_gn_fused(case, dtype):
     bd = bias.cuda()
     rd = G.to_nhwc(res, dtype) if res is not None else None
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
-    stats = torch.full((N * H * W // 32, Cout, 2), float("nan"), device="cuda")
+    stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
     L.call("ivid_conv3x3_gn", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), up, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(rd),
            res_mode, N, H, W, Cout, L.ptr(stats), G.stream())
     torch.cuda.synchronize()
@@ -163,7 +164,8 @@ def test_conv3x3_gn_fused(case, dtype):
     G.report(f"conv3x3_gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
-    o = out.float().reshape(-1, 32, Cout)
+    # one block = 4 image rows x 32 columns; blocks ordered (image, 4-row band, 32-column strip)
+    o = out.float().reshape(N, H // 4, 4, W // 32, 32, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 128, Cout)
     sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
     assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
 
@@ -258,10 +260,16 @@ def test_gn_finalize_from_two_fused_partial_buffers_matches_single_buffer():
     ab1 = torch.empty(N, Cc, 2, device="cuda")
     ab2 = torch.empty(N, Cc, 2, device="cuda")
     L.call("ivid_gn_finalize", L.ptr(part), nch, N, Cc, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0, L.ptr(ab1), G.stream())
-    L.call("ivid_gn_finalize2", L.ptr(p0), C0, L.ptr(p1), C1, nch, N, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0,
+    L.call("ivid_gn_finalize2", L.ptr(p0), C0, nch, L.ptr(p1), C1, nch, N, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0,
            L.ptr(ab2), G.stream())
+    # second source with a coarser block size (its producer used a different tile)
+    p1c = p1.reshape(N, nch // 2, 2, C1, 2).sum(2).contiguous()
+    ab3 = torch.empty(N, Cc, 2, device="cuda")
+    L.call("ivid_gn_finalize2", L.ptr(p0), C0, nch, L.ptr(p1c), C1, nch // 2, N, HW, 32, 1e-5, L.ptr(gamma), L.ptr(beta), None, 0, 0,
+           L.ptr(ab3), G.stream())
     torch.cuda.synchronize()
     assert torch.equal(ab1, ab2)
+    assert torch.allclose(ab1, ab3, rtol=1e-5, atol=1e-6)
     y = F.group_norm(x.permute(0, 2, 1), 32, gamma.cpu(), beta.cpu(), 1e-5)
     got = x.permute(0, 2, 1) * ab1[:, :, 0:1].cpu() + ab1[:, :, 1:2].cpu()
     assert common.rel_l2(got, y) < 1e-5

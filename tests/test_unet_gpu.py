@@ -210,6 +210,41 @@ def test_config1_small128_ddim10_matches_reference_golden():
     assert e4 < PARITY_BAR
 
 
+def test_sr256_forward_and_superres_chain_match_oracle():
+    """BASELINE config 5's model (SR 128->256: 8 input channels, attention at T = 4096 / 1024 / 256): one fp32 forward
+    against the oracle on the host, and SuperResCFG + DDIM through `super_resolve` on the 64-px mini variant."""
+    from ivid_amd.diffusion import frameworks
+    from ivid_amd.inference.superres import super_resolve
+    m, sd = build(C.SR256, 6, "fp32")
+    x = C.seeded_randn(61, 1, 8, 256, 256)
+    t = torch.full((1,), 321, dtype=torch.long)
+    cls = torch.tensor([17])
+    out = m(x.cuda(), t.cuda(), cls.cuda()).cpu()
+    ref = adm_oracle.unet_forward(sd, C.SR256, x, t, cls)
+    e = C.rel_l2(out, ref)
+    G.report("unet/sr256_fwd/fp32", rel_l2=e)
+    assert e < 1e-4
+    del m
+    # chain: low-res views -> bilinear x2 + concat (sr_cfg.py:31-36) -> CFG DDIM (4 steps)
+    ms, sds = build(C.MINI_SR, 7, "fp32")
+    fw = frameworks.SuperResCFG(ms, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    low = C.seeded_randn(62, 2, 4, 32, 32).clamp(-1, 1)
+    cls2 = torch.tensor([4, 9])
+    torch.manual_seed(3)
+    ours = super_resolve(fw, low.cuda(), classes=cls2.cuda(), steps=4, strength=3.0, noise_fn=_cpu_noise_fn()).cpu()
+    import torch.nn.functional as F
+    um = lambda a, b, c: adm_oracle.unet_forward(sds, C.MINI_SR, a, b, c)
+
+    def eps(x_t, tt):
+        ci = torch.cat([x_t, F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False)], dim=1)
+        return 4.0 * um(ci, tt, cls2) - 3.0 * um(ci, tt, None)
+    torch.manual_seed(3)
+    ref = sampler_oracle.ddim_sample(eps, torch.randn(2, 4, 64, 64), 4, sampler_oracle.linear_betas(1000))["samples"]
+    e2 = C.rel_l2(ours, ref)
+    G.report("chain/mini_superres", samples=e2)
+    assert ours.shape == (2, 4, 64, 64) and e2 < PARITY_BAR
+
+
 def test_full_size_properties_large_bf16_bs64():
     """BASELINE config 2 shape (large model, bs 64, stacked CFG = batch 128) where the CPU oracle is too slow:
     size-independent properties — finite outputs, row i of the batch equals the bs-1 forward of sample i
