@@ -51,8 +51,9 @@ int ivid_event_destroy(void* ev);
  *               +8 = also prefetch the next channel chunk into L2 (experiment: measured 5-15 % slower, off by default)
  *   stats     : NULL, or fp32 [N*H*W/blk][Cout][2]: per block of blk consecutive pixels and output channel, sum and sum
  *               of squares of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this
- *               epilogue (same layout as ivid_gn_partial with H*W/blk chunks per image); blk = one wave's rows =
- *               ivid_conv2d_stats_block(...) (64 / 128 / 32 for tile_cfg 1 / 2 / 3), H*W % blk must be 0 */
+ *               epilogue (same layout as ivid_gn_partial with H*W/blk chunks per image); blk =
+ *               ivid_conv2d_stats_block(...) = 64 (32 for the narrow tile) independent of the tile, so the summation
+ *               order — and with it every sample's result — does not depend on the batch size; H*W % blk must be 0 */
 int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias,
                 void* out, const void* res, int res_mode, int out_mode, int N, int H, int W, int Cout, int taps,
                 int tile_cfg, float* stats, void* stream);

@@ -274,7 +274,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       constexpr int LPR = WTN / VE;   // lanes per slab row
       constexpr int RPP = 64 / LPR;   // rows per pass
       const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-      if (mi == 0) {
+      // statistics blocks are ALWAYS 64 consecutive pixels (32 for the narrow tile), whatever tile the launch uses:
+      // the fp32 summation order is then independent of the batch-size-dependent tile choice, so a sample's result
+      // is bit-identical in any batch (in bf16 mode a 1e-7 change of a GroupNorm coefficient decorrelates rounding
+      // decisions downstream up to the bf16 noise floor)
+      constexpr int FL = MI >= 2 ? 2 : 1;  // fragments per statistics block
+      if (mi % FL == 0) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
       }
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
         }
       }
-      if (p.stats && mi == MI - 1) {  // one partial per wave: WTM consecutive pixels
+      if (p.stats && mi % FL == FL - 1) {
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -348,9 +353,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
         }
         const int n = nbase + lc;
-        const int wbase = m0 + wm * WTM;  // first pixel of this wave's block
+        const int wbase = m0 + wm * WTM + (mi / FL) * (FL * 32);  // first pixel of this block
         if (lr == 0 && wbase < p.M && n < Cout) {
-          float* sp = p.stats + ((size_t)(wbase / WTM) * Cout + n) * 2;
+          float* sp = p.stats + ((size_t)(wbase / (FL * 32)) * Cout + n) * 2;
 #pragma unroll
           for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
         }
@@ -420,8 +425,8 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
     tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1));
   }
-  if (stats) {  // one partial per wave = per WTM pixels; a block must not straddle two images
-    const int gran = (tile_cfg & 7) == 2 ? 128 : ((tile_cfg & 7) == 3 ? 32 : 64);
+  if (stats) {  // a statistics block must not straddle two images
+    const int gran = (tile_cfg & 7) == 3 ? 32 : 64;
     if (out_mode != 0 || (H * W) % gran) return ivid_set_error("conv: stats need NHWC output and H*W % block == 0", hipSuccess);
   }
   const bool pf = (tile_cfg & 8) != 0;   // bit 3 of tile_cfg ENABLES the L2 prefetch (measured slower: off by default)
@@ -445,5 +450,5 @@ extern "C" int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_c
     const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
     cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1);
   }
-  return cfg == 2 ? 128 : (cfg == 3 ? 32 : 64);
+  return cfg == 3 ? 32 : 64;
 }

@@ -22,7 +22,7 @@ def main():
     n = int(os.environ.get("N", "128"))
     dtype = _lib.BF16 if os.environ.get("DTYPE", "bf16") == "bf16" else _lib.F32
     tdt = torch.bfloat16 if dtype == _lib.BF16 else torch.float32
-    cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,17,18").split(",")]
+    cfgs = [int(c) for c in os.environ.get("CFGS", "-1,1,2").split(",")]   # -1 = fused conv3x3_gn kernel
     reps = int(os.environ.get("REPS", "5"))
     lib = _lib.load()
     stream = torch.cuda.Stream()
@@ -36,10 +36,18 @@ def main():
         b = torch.randn(cout, device="cuda")
         out = torch.empty(n, h, h, cout, device="cuda", dtype=tdt)
         flop = 2.0 * n * h * h * cout * taps * cin
+        ab = torch.rand(n, cin, 2, device="cuda") + 0.5
         for cfg in cfgs:
+            if cfg == -1 and (taps != 9 or h < 32):
+                continue
+
             def launch():
-                _lib.check(lib.ivid_conv2d(dtype, x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 0, 0,
-                                           n, h, h, cout, taps, cfg, None, sp), "conv")
+                if cfg == -1:   # the fused GN-apply + SiLU + conv3x3 kernel
+                    _lib.check(lib.ivid_conv3x3_gn(dtype, x.data_ptr(), cin, None, 0, ab.data_ptr(), 0, w.data_ptr(), b.data_ptr(),
+                                                   out.data_ptr(), None, 0, n, h, h, cout, None, sp), "conv3x3_gn")
+                else:
+                    _lib.check(lib.ivid_conv2d(dtype, x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 0, 0,
+                                               n, h, h, cout, taps, cfg, None, sp), "conv")
             launch()
             torch.cuda.synchronize()
             e0, e1 = C.c_void_p(), C.c_void_p()

@@ -8,7 +8,7 @@ wc -l gpurun_out/pmc/counters_available.txt
 run() { # name, counters...
   name=$1; shift
   rm -rf gpurun_out/pmc/$name
-  SHAPES_ONLY="${SHAPES_ONLY:-1,3}" CFGS="${CFGS:-2}" REPS=2 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -o p -- python scripts/conv_bench.py > gpurun_out/pmc/$name.log 2>&1
+  SHAPES_ONLY="${SHAPES_ONLY:-1,3}" CFGS="${CFGS:--1}" REPS=2 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -o p -- python scripts/conv_bench.py > gpurun_out/pmc/$name.log 2>&1
   echo "$name exit $?"
   f=$(find gpurun_out/pmc/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python scripts/pmc_summary.py "$f" > gpurun_out/pmc/$name.summary.txt && cat gpurun_out/pmc/$name.summary.txt

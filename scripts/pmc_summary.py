@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 acc = defaultdict(lambda: defaultdict(list))
 for r in rows:
     k = r.get("Kernel_Name", "?")
-    if "conv_igemm" not in k and len(sys.argv) < 3:
+    if "conv_igemm" not in k and "conv3x3_fused" not in k and len(sys.argv) < 3:
         continue
     key = (k[:70], r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))

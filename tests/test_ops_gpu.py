@@ -75,6 +75,7 @@ CONV_CASES = [
     ("3x3_bigtile", 2, 32, 32, 128, 0, 512, 3, 1, 0, 2),
     ("3x3_bigtile_masks", 1, 24, 24, 64, 64, 320, 3, 0, 0, 2),
     ("3x3_64px_auto", 1, 64, 64, 256, 0, 256, 3, 0, 0, 0),
+    ("3x3_bigtile_512tiles_res", 8, 128, 128, 64, 0, 256, 3, 1, 0, 2),
     ("3x3_narrow_nchw_out4", 2, 32, 32, 128, 0, 4, 3, 0, 1, 3),
     ("3x3_narrow_auto_c32", 1, 16, 16, 64, 0, 32, 3, 1, 0, 0),
 ]
