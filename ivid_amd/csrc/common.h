@@ -55,10 +55,22 @@ template <> __device__ __forceinline__ bf16x8 f32_to_vec<__bf16>(const float* f)
 // HBM-bound only as long as the VALU work per 16-byte piece stays small
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// Async 16-byte global -> LDS copy (global_load_lds_dwordx4). LDS destination is
-// wave-uniform base + lane*16; the global source address is per lane.
+// Async 16-byte global -> LDS copy (global_load_lds_dwordx4): LDS destination = wave-uniform base + lane*16, the
+// global source address is per lane.
+// Issued through inline assembly ON PURPOSE: hipcc models the builtin as a FLAT operation that touches both memory
+// and LDS and then forces every later `s_waitcnt lgkmcnt` to 0 until the next vmcnt(0) — which serialises the
+// ds_read -> MFMA software pipeline of the conv kernels.  With the asm form the compiler counts its own LDS reads
+// exactly; the DMA itself is ordered by hand (wait_vmcnt0() + barrier before the stage is read, as before).  No other
+// code in these kernels uses M0.
+__device__ __forceinline__ unsigned lds_addr_of(const void* lds_ptr) {  // wave-uniform LDS byte address in an SGPR
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds_ptr);
+}
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr_of(lds_wave_base)) : "memory");
+}
+// same with a wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit VALU address arithmetic
+__device__ __forceinline__ void glds16_s(const void* base, unsigned voff, void* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr_of(lds_wave_base)) : "memory");
 }
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -20,6 +20,8 @@
 //   schedule  : K-step = (chunk, tap); taps are unrolled, each tap issues the raw load of ONE halo piece of the NEXT
 //               chunk and, three taps later (right after the step's barrier, when everything in flight has landed),
 //               transforms + stores it: at most 3 pieces (12 VGPRs) are in flight and the VALU work is spread evenly.
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "internal.h"
 
@@ -60,13 +62,20 @@ constexpr int TH = 8, TW = 32;             // output tile (pixels)
 constexpr int HW_ = TW + 2, HH_ = TH + 2;  // halo
 constexpr int HROWS = HH_ * HW_;           // 340 halo pixels
 constexpr int BN = 256, NT = 512;
-constexpr int A_BYTES = HROWS * 128;       // one halo image
+// Halo image in LDS: one row per halo pixel = 128 B of channels + a 16-byte pad.  The odd 16-byte stride (9 slots)
+// spreads the 16 lanes of a ds_read_b128 group over all 16 bank slots for ANY row shift, so every fragment address is
+// ONE per-lane base + a compile-time offset (tap, fragment, k-piece) -- no swizzle arithmetic in the K loop.  The pads of
+// rows 0..31 carry the GroupNorm coefficients of the image's channel chunk.
+constexpr int AROW = 144;
+constexpr int A_BYTES = HROWS * AROW;      // 48,960
 constexpr int B_BYTES = BN * 128;
 constexpr int PIECES = (HROWS + 63) / 64;  // halo pieces per thread (64 halo pixels per pass of 512 threads)
-constexpr int AB_BYTES = 512;                 // (a,b) pairs of one 128-byte channel chunk: 64 ch x 2 floats (32 ch for fp32)
-constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES + 2 * AB_BYTES;
+constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 163,456 of the CU's 163,840
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <typename T>
+// AB: development ablation mask (always 0 in the product; -DIVID_DEV_ABLATE + IVID_FUSED_ABLATE select others):
+//     1 no weight re-streaming, 2 no halo pipeline, 4 no epilogue global traffic, 8 no MFMAs
+template <typename T, int AB = 0>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -76,7 +85,6 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BYTES;
-  char* const sAB0 = smem + 2 * A_BYTES + 2 * B_BYTES;  // double-buffered GroupNorm coefficients of a chunk
 
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   // tile id -> (image, tile row, tile col, cout tile); cout tiles of one pixel tile are neighbours (shared A in L2)
@@ -96,78 +104,115 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   const size_t Ktot = (size_t)9 * Ctot;
   const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;
 
-  // ---- halo staging: thread handles channel piece cpc = tid&7 of halo pixels hrow = j*64 + (tid>>3), j = 0..5.
-  //      Nothing is precomputed per piece (6 pieces x pointers would cost ~40 VGPRs): the pixel decode is a handful of
-  //      integer ops, executed once per piece and chunk. ----
+  // ---- halo staging: thread handles channel piece cpc = tid&7 (16 bytes) of halo pixels hrow = 64 j + (tid>>3),
+  //      j = 0..5.  Per piece only the source pixel index is kept (6 VGPRs + one validity bit mask). ----
   const int cpc = tid & 7;
   const int hrow0 = tid >> 3;
-  struct Piece { size_t pix; int lds; bool ok, act; };
-  auto piece_desc = [&](int j) -> Piece {
-    Piece d;
+  int pix[PIECES];       // source pixel index INSIDE the image (0 when padded / idle: valid memory, zeroed later)
+  unsigned okbits = 0;   // bit j: halo pixel of piece j lies inside the image
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
     const int hrow = j * 64 + hrow0;
-    d.act = hrow < HROWS;
     const int hy = hrow / HW_, hx = hrow - hy * HW_;
     const int y = y0 + hy - 1, x = x0 + hx - 1;
-    d.ok = d.act && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    const bool ok = hrow < HROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
     const int ys = p.up ? y >> 1 : y, xs = p.up ? x >> 1 : x;
-    d.pix = ((size_t)img * Hs + ys) * Ws + xs;
-    d.lds = hrow * 128 + ((cpc ^ ((hrow >> 1) & 7)) << 4);
-    return d;
-  };
-  // wave-uniform description of where channel chunk ch lives (src0 or the skip tensor src1)
-  struct ChunkSrc { const char* base; int C, coff; };
+    pix[j] = ok ? ys * Ws + xs : 0;
+    okbits |= (ok ? 1u : 0u) << j;
+  }
+  const int st_lds = hrow0 * AROW + cpc * 16;   // piece j adds 64 j rows
+  const bool act5 = hrow0 < HROWS - 5 * 64;     // piece 5 exists for the first 20 halo rows only
+  // wave-uniform description of where channel chunk ch lives (src0 or the skip tensor src1): addresses are a
+  // wave-uniform 64-bit base + a 32-bit lane offset (no 64-bit VALU arithmetic, no address VGPR pairs)
+  const size_t img_px = (size_t)img * Hs * Ws;
+  const char* const src0_img = p.src0 + img_px * p.C0 * sizeof(T);
+  const char* const src1_img = p.src1 + img_px * p.C1 * sizeof(T);
+  struct ChunkSrc { const char* base; int cb; };  // cb = bytes per source pixel
   auto chunk_src = [&](int ch) -> ChunkSrc {
     const int cbase = ch * BKE;
     ChunkSrc c;
-    if (cbase >= p.C0) { c.base = p.src1; c.C = p.C1; c.coff = cbase - p.C0; }
-    else               { c.base = p.src0; c.C = p.C0; c.coff = cbase; }
+    if (cbase >= p.C0) { c.base = src1_img + (size_t)(cbase - p.C0) * sizeof(T); c.cb = p.C1 * (int)sizeof(T); }
+    else               { c.base = src0_img + (size_t)cbase * sizeof(T); c.cb = p.C0 * (int)sizeof(T); }
     return c;
   };
+  auto load_piece = [&](int j, const ChunkSrc& cs) -> vec_t {  // raw 16 bytes of halo piece j
+    return *(const vec_t*)(cs.base + (size_t)(__umul24(pix[j], cs.cb) + cpc * 16));
+  };
+
+  // ---- GroupNorm coefficients of a chunk (BKE channels x (a,b) fp32): lanes 0..BKE/2-1 of wave 0 fetch 16 bytes =
+  //      (a0,b0,a1,b1) each and park them, re-paired as (a0,a1,b0,b1) for packed math, in the pad of halo row `lane` of
+  //      the image the chunk is transformed INTO ----
   const float* abn = p.ab + (size_t)img * Ctot * 2;
-
-  // ---- weight staging (as conv_igemm): thread owns 4 pieces of the [256][128 B] slab, rows 64 apart (same swizzle) ----
-  const int b_row = tid >> 3;
-  const char* b_ptr0 = p.w + ((size_t)(n0 + b_row) * Ktot + (((tid & 7) ^ ((b_row >> 1) & 7)) * VE)) * sizeof(T);
-  const size_t b_stride = (size_t)64 * Ktot * sizeof(T);
-  auto issue_b = [&](int stage, int ch, int tap) {
-    char* sB = sB0 + stage * B_BYTES;
-    const size_t koff = ((size_t)tap * Ctot + (size_t)ch * BKE) * sizeof(T);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char* g = (n0 + b_row + 64 * i < p.Cout) ? b_ptr0 + i * b_stride + koff : p.zero;
-      glds16(g, sB + (i * NT + wave * 64) * 16);
-    }
+  auto ab_load = [&](int ch) -> f32x4 {
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && lane < BKE / 2) q = *(const f32x4*)(abn + (size_t)ch * BKE * 2 + lane * 4);
+    return q;
   };
-  // GroupNorm coefficients of chunk ch -> LDS by LDS-DMA from wave 0 (BKE channels x (a,b) x 4 B = 512 B for bf16,
-  // 256 B for fp32: exactly BKE/2 lanes x 16 B, never past the end of the coefficient buffer): kept out of the VGPRs
-  auto issue_ab = [&](int ch) {
-    if (wave == 0 && lane < BKE / 2)
-      glds16((const char*)(abn + (size_t)ch * BKE * 2) + lane * 16, sAB0 + (ch & 1) * AB_BYTES);
+  auto ab_store = [&](const f32x4& q, char* sAdst) {
+    if (wave == 0 && lane < BKE / 2) *(f32x4*)(sAdst + lane * AROW + 128) = f32x4{q[0], q[2], q[1], q[3]};
   };
-
-  // raw load of halo piece j of channel chunk ch (zero page for padding / idle lanes)
-  auto load_piece = [&](int j, const ChunkSrc& cs) -> vec_t {
-    const Piece d = piece_desc(j);
-    const char* g = cs.base + (d.pix * cs.C + cs.coff) * sizeof(T) + cpc * 16;
-    g = d.ok ? g : p.zero;
-    return *(const vec_t*)g;
-  };
-  // y = silu(x*a + b), zero outside the image, stored to the swizzled halo image of chunk ch
-  auto store_piece = [&](int j, const vec_t& raw, int ch, char* sA) {
-    const Piece d = piece_desc(j);
-    if (!d.act) return;
-    const float* abl = (const float*)(sAB0 + (ch & 1) * AB_BYTES) + cpc * VE * 2;
+  // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction), zero outside the image
+  auto xform_store = [&](int j, const vec_t& raw, char* sAdst) {
+    const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
     float f[VE];
     vec_to_f32<T>(raw, f);
 #pragma unroll
     for (int e = 0; e < VE; e += 2) {
-      const f32x4 q = *(const f32x4*)(abl + e * 2);  // a[e], b[e], a[e+1], b[e+1]
-      const float v0 = silu_f(f[e] * q[0] + q[1]), v1 = silu_f(f[e + 1] * q[2] + q[3]);
-      f[e] = d.ok ? v0 : 0.f;
-      f[e + 1] = d.ok ? v1 : 0.f;
+      const f32x4 q = *(const f32x4*)(cf + (e / 2) * AROW);
+      const f32x2 x = {f[e], f[e + 1]};
+      const f32x2 v = x * f32x2{q[0], q[1]} + f32x2{q[2], q[3]};
+      const f32x2 t = v * -1.4426950408889634f;
+      f32x2 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      d = d + 1.0f;
+      const f32x2 y = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+      f[e] = y[0];
+      f[e + 1] = y[1];
     }
-    *(vec_t*)(sA + d.lds) = f32_to_vec<T>(f);
+    vec_t o = f32_to_vec<T>(f);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
+    u32x4 ob = __builtin_bit_cast(u32x4, o);
+    ob &= keep;
+    if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
   };
+
+  // ---- weight staging (as conv_igemm): thread owns 4 pieces of the [256][128 B] slab, rows 64 apart (same swizzle) ----
+  const int b_row = tid >> 3;
+  unsigned b_voff[4];  // rows past Cout are clamped: they produce columns the epilogue never stores
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(n0 + b_row + 64 * i, p.Cout - 1);
+    b_voff[i] = (unsigned)((size_t)row * Ktot * sizeof(T)) + (((tid & 7) ^ ((b_row >> 1) & 7)) << 4);
+  }
+  auto issue_b = [&](int stage, int ch, int tap) {
+    char* sB = sB0 + stage * B_BYTES;
+    const char* wk = p.w + ((size_t)tap * Ctot + (size_t)ch * BKE) * sizeof(T);  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_s(wk, b_voff[i], sB + (i * NT + wave * 64) * 16);
+  };
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // weight fragment (ni = 0, k-piece 0) inside a stage; fragment ni adds 32 rows = 4096 B (same swizzle), k-piece kk
+  // flips address bits 5-6:  ((2kk + fhalf) ^ sw) << 4  ==  ((fhalf ^ sw) << 4) ^ (kk << 5)
+  const int b_addr0 = (wn * WTN + frow) * 128 + ((fhalf ^ (((wn * WTN + frow) >> 1) & 7)) << 4);
+  // halo fragment base = (fragment 0, lane pixel, k-piece 0) for the TOP-LEFT tap; fragment mi adds mi halo rows of
+  // pixels (HW_ each), tap (g, t) adds g*HW_ + t pixels, k-piece kk adds 32 B: all compile-time ds_read offsets
+  const int a_base = ((wm * 4) * HW_ + frow) * AROW + fhalf * 16;
+
+  // ---------------- prologue: everything of (chunk 0, tap 0) in ONE memory round trip ----------------
+  {
+    const f32x4 q0 = ab_load(0);
+    issue_b(0, 0, 0);
+    const ChunkSrc cs0 = chunk_src(0);
+    vec_t rawp[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) rawp[j] = load_piece(j, cs0);
+    ab_store(q0, sA0);
+    wait_vmcnt0();
+    __syncthreads();  // coefficients of chunk 0 visible
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) xform_store(j, rawp[j], sA0);
+  }
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -177,92 +222,92 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int b_off0 = (wn * WTN + frow) * 128;          // fragment ni adds 32 rows (swizzle unchanged: rows 32 apart)
-  const int b_sw0 = ((wn * WTN + frow) >> 1) & 7;
-  // halo row of (fragment 0, lane pixel) for the CENTRE tap; fragment mi adds mi*HW_, tap (dy,dx) adds dy*HW_ + dx
-  const int a_hrow0 = (wm * 4 + 1) * HW_ + frow + 1;
-
-  // ---------------- prologue: halo of chunk 0, weights of (chunk 0, tap 0) ----------------
-  issue_ab(0);
-  wait_vmcnt0();
-  __syncthreads();
-  {
-    const ChunkSrc cs0 = chunk_src(0);
-#pragma unroll 1
-    for (int j = 0; j < PIECES; ++j) {
-      const vec_t raw = load_piece(j, cs0);
-      store_piece(j, raw, 0, sA0);
-    }
-  }
-  issue_b(0, 0, 0);
-
   // ---------------- main loop ----------------
-  // K-step = (chunk, tap), tap = 3*g + t with (dy, dx) = (g-1, t-1).  The t loop is unrolled so the three in-flight halo
-  // pieces live in statically indexed registers: at tap 3g+t slot t is consumed (piece 3(g-1)+t, issued three taps
-  // ago) and refilled (piece 3g+t of the next chunk).
-  int kstep = 0;  // running K-step index (selects the weight stage)
-  for (int ch = 0; ch < chunks; ++ch) {
-    const char* sA = sA0 + (ch & 1) * A_BYTES;
+  // K-step = (chunk, tap), tap = 3g + t with (dy, dx) = (g-1, t-1); the 9 taps of a chunk are unrolled (straight-line
+  // code, static register indices).  Halo pipeline of the NEXT chunk: at tap 3g+t slot t of raw[] is consumed (piece
+  // 3(g-1)+t, issued three taps ago: transformed and stored) and refilled (piece 3g+t); its coefficients are fetched at
+  // tap 0 and parked in LDS at tap 1.  The two wave groups (wm = 0 / 1: waves w and w+4 share a SIMD) run the step's
+  // two halves in OPPOSITE order: while one group transforms its halo piece (VALU + transcendental pipes) the other
+  // owns the matrix pipe, then they swap; both meet at the next step's barrier.  Fragment registers rotate: a fragment
+  // is re-requested for k-piece kk+1 right after its last MFMA of k-piece kk has been issued.
+  auto chunk_body = [&](const int ch, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
     char* sAn = sA0 + ((ch + 1) & 1) * A_BYTES;
-    const bool more = ch + 1 < chunks;
-    const ChunkSrc csn = chunk_src(more ? ch + 1 : ch);
+    const ChunkSrc csn = chunk_src(MORE ? ch + 1 : ch);
     vec_t raw[3];
-#pragma unroll 1
+    f32x4 abq;
+#pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t, ++kstep) {
+      for (int t = 0; t < 3; ++t) {
+        const int tap = 3 * g + t;
+        const bool do_store = !(AB & 2) && MORE && g >= 1;
+        const bool do_load = !(AB & 2) && MORE && g <= 1;
         wait_vmcnt0();
         __syncthreads();  // weights of this step landed; halo writes of earlier steps visible; previous reads finished
-        const char* sB = sB0 + (kstep & 1) * B_BYTES;
-        // ---- first fragments of this step (requested first: their LDS latency hides behind the transform below) ----
-        const int tapoff = (g - 1) * HW_ + (t - 1);
-        vec_t a[MI], b[NI];
-        int a_addr[MI];
-        // opaque to the optimiser: otherwise it hoists all 9 taps x 4 fragments x 4 k-pieces of swizzled LDS addresses
-        // out of the chunk loop (144 values -> spills); recomputing them costs 3 VALU ops per ds_read
-        int hbase = a_hrow0;
-        asm volatile("" : "+v"(hbase));
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int hr = hbase + mi * HW_ + tapoff;
-          a_addr[mi] = hr * 128;
-          a[mi] = *(const vec_t*)(sA + a_addr[mi] + ((fhalf ^ ((hr >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off0 + ni * 4096 + ((fhalf ^ b_sw0) << 4));
-        // ---- consume the halo piece issued three taps ago (landed: everything in flight was drained above) ----
-        if (more && g >= 1) store_piece(3 * (g - 1) + t, raw[t], ch + 1, sAn);
-        // ---- issue: weights of the next K-step, one raw halo piece of the next chunk ----
-        {
-          const bool last = (g == 2) && (t == 2);
-          const int ntap = last ? 0 : 3 * g + t + 1;
-          const int nch = last ? ch + 1 : ch;
-          if (nch < chunks) issue_b((kstep + 1) & 1, nch, ntap);
-        }
-        if (more && g <= 1) {
-          if (g == 0 && t == 0) issue_ab(ch + 1);
+        const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
+        const int b_off = par * B_BYTES + b_addr0;
+        // ---- issue first: weights of the next K-step (a whole step to land), one raw halo piece of the next chunk ----
+        if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        vec_t cur;
+        if (do_store) cur = raw[t];
+        if (do_load) {
+          if (tap == 0) abq = ab_load(ch + 1);
+          if (tap == 1) ab_store(abq, sAn);
           raw[t] = load_piece(3 * g + t, csn);
         }
-        // ---- MFMAs; the next fragments are requested as soon as the current ones have been issued ----
+        // ---- fragments of k-piece 0 ----
+        vec_t a[MI], b[NI];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW);
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
+        auto mma_block = [&]() {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) Mma2<T>::run(a[mi], b[ni], acc[mi][ni]);
-          if (kk < 3) {
-            const int piece = 2 * (kk + 1) + fhalf;
+          for (int kk = 0; kk < 4; ++kk) {
+            const int xo = (kk + 1) << 5;
+            const bool pf = kk < 3;
+            auto mma = [&](int mi, int ni) {
+              if (AB & 8) asm volatile("" ::"v"(a[mi]), "v"(b[ni]));
+              else Mma2<T>::run(a[mi], b[ni], acc[mi][ni]);
+            };
+            auto a_next = [&](int mi) { a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW + (kk + 1) * 32); };
+            mma(0, 0); mma(1, 0); mma(2, 0); mma(3, 0);
+            if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
+            mma(0, 1);
+            if (pf) a_next(0);
+            mma(1, 1);
+            if (pf) a_next(1);
+            mma(2, 1);
+            if (pf) a_next(2);
+            mma(3, 1);
+            if (pf) {
+              a_next(3);
+              b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
+              // pin the rotation: 4 MFMA, read, then (MFMA, read) x 4 (the last one 2 reads)
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              a[mi] = *(const vec_t*)(sA + a_addr[mi] + ((piece ^ ((a_addr[mi] >> 8) & 7)) << 4));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off0 + ni * 4096 + ((piece ^ b_sw0) << 4));
+              for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
           }
-        }
+        };
+        if (do_store && wm == 0) xform_store(3 * (g - 1) + t, cur, sAn);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block();
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_store && wm != 0) xform_store(3 * (g - 1) + t, cur, sAn);
       }
     }
-  }
+  };
+  for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
+  chunk_body(chunks - 1, std::false_type{});
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   wait_vmcnt0();
@@ -295,7 +340,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       const int row = ps * RPP + lr;
       const size_t m = mbase + row;
       const int n = nbase + lc;
-      if (n < Cout) {
+      if (n < Cout && (!(AB & 4) || p.N < 0)) {
         float v[VE];
 #pragma unroll
         for (int e = 0; e < VE; e += 4) {
@@ -353,8 +398,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   }
 }
 
-template <typename T> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T>;
+template <typename T, int AB = 0> int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T, AB>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -380,6 +425,11 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
   if (up && ((H | W) & 1)) return ivid_set_error("conv3x3_gn: upsample needs even H,W", hipSuccess);
   if (res_mode < 0 || res_mode > 2 || (res_mode && !res)) return ivid_set_error("conv3x3_gn: bad residual", hipSuccess);
   if (!ab) return ivid_set_error("conv3x3_gn: ab missing", hipSuccess);
+  {  // the kernel addresses one image / the weight matrix with 32-bit byte offsets from a 64-bit wave-uniform base
+    const size_t hs = up ? H / 2 : H, ws = up ? W / 2 : W, cmax = C0 > C1 ? C0 : C1;
+    if (hs * ws * cmax * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * (C0 + C1) * esz >= ((size_t)1 << 32))
+      return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
+  }
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;
@@ -387,6 +437,21 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.up = up ? 1 : 0; a.res_mode = res_mode;
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
+#ifdef IVID_DEV_ABLATE
+  if (dtype == IVID_BF16) {
+    static const int ablate = getenv("IVID_FUSED_ABLATE") ? atoi(getenv("IVID_FUSED_ABLATE")) : 0;
+    switch (ablate) {
+      case 1: return launch_fused<__bf16, 1>(a, (hipStream_t)stream);
+      case 2: return launch_fused<__bf16, 2>(a, (hipStream_t)stream);
+      case 3: return launch_fused<__bf16, 3>(a, (hipStream_t)stream);
+      case 4: return launch_fused<__bf16, 4>(a, (hipStream_t)stream);
+      case 7: return launch_fused<__bf16, 7>(a, (hipStream_t)stream);
+      case 8: return launch_fused<__bf16, 8>(a, (hipStream_t)stream);
+      case 15: return launch_fused<__bf16, 15>(a, (hipStream_t)stream);
+      default: break;
+    }
+  }
+#endif
   if (dtype == IVID_BF16) return launch_fused<__bf16>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
 }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       const bool inb = (unsigned)(pf_y + dy) < (unsigned)p.H && (unsigned)(pf_x + dx) < (unsigned)p.W;
       const char* g = (second ? pf_base1 : pf_base0) + delta + pf_dist * 128;
       g = (inb && same_src) ? g : p.zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(smem + 2 * STAGE + wave * 256), 4, 0, 0);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_addr_of(smem + 2 * STAGE + wave * 256)) : "memory");
     }
     if (++ld_tap == p.taps) {
       ld_tap = 0;
