@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     float f[VE];
     vec_to_f32<T>(raw, f);
 #pragma unroll
-    for (int e = 0; e < VE; e += 2) {
+    for (int e = 0; e < ((AB & 32) ? 0 : VE); e += 2) {
       const f32x4 q = *(const f32x4*)(cf + (e / 2) * AROW);
       const f32x2 x = {f[e], f[e + 1]};
       const f32x2 v = x * f32x2{q[0], q[1]} + f32x2{q[2], q[3]};
@@ -244,19 +244,30 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         const int tap = 3 * g + t;
         const bool do_store = !(AB & 2) && MORE && g >= 1;
         const bool do_load = !(AB & 2) && MORE && g <= 1;
-        wait_vmcnt0();
-        __syncthreads();  // weights of this step landed; halo writes of earlier steps visible; previous reads finished
+        // ---------- phase 1 of the step ("other": issue, fragment fetch, halo transform) ----------
+        // Counted waits: the raw halo piece of the latest issue window (always the newest VMEM operation of a wave,
+        // issued AFTER the weights) may stay in flight -- it is consumed three steps later; everything older has landed.
+        const bool prev_loaded = !(AB & 2) && MORE && tap >= 1 && tap <= 6;
+        if (prev_loaded) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else wait_vmcnt0();
+        __syncthreads();  // barrier X
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
-        // ---- issue first: weights of the next K-step (a whole step to land), one raw halo piece of the next chunk ----
-        if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
+        // issue window would make it wait for that window's weights)
         vec_t cur;
         if (do_store) cur = raw[t];
-        if (do_load) {
-          if (tap == 0) abq = ab_load(ch + 1);
-          if (tap == 1) ab_store(abq, sAn);
-          raw[t] = load_piece(3 * g + t, csn);
-        }
+        asm volatile("" : "+v"(cur));  // pins the copy (and the compiler's vmcnt for it) here
+        if (do_load && tap == 1) ab_store(abq, sAn);
+        // issue window of the step: weights of the NEXT K-step, then one raw halo piece of the next chunk
+        auto issue_window = [&]() {
+          if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+          if (do_load) {
+            if (tap == 0) abq = ab_load(ch + 1);
+            raw[t] = load_piece(3 * g + t, csn);
+          }
+        };
+        if (wm == 1) issue_window();  // the lagging group's window: global time = the leading group's MFMA phase
         // ---- fragments of k-piece 0 ----
         vec_t a[MI], b[NI];
 #pragma unroll
@@ -298,16 +309,33 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
             }
           }
         };
-        if (do_store && wm == 0) xform_store(3 * (g - 1) + t, cur, sAn);
+        if (do_store) xform_store(3 * (g - 1) + t, cur, sAn);
+        // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
+        if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else wait_vmcnt0();
+        __syncthreads();  // barrier Y
+        if (wm == 0) issue_window();  // the leading group's window (the stage it overwrites was read until barrier Y)
         __builtin_amdgcn_sched_barrier(0);
+        if (AB & 64) __builtin_amdgcn_s_setprio(1);
         mma_block();
+        if (AB & 64) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (do_store && wm != 0) xform_store(3 * (g - 1) + t, cur, sAn);
       }
     }
   };
+  // Ping-pong: wave group wm = 1 runs ONE BARRIER behind group wm = 0 (waves w and w+4 share a SIMD).  Every step has
+  // two barriers (X, Y); while one group executes its MFMA phase the other fetches fragments, transforms its halo piece
+  // and issues loads, so the matrix pipe always has a group whose fragments are already in registers.
+  // Hazards under the skew (global barrier index n; group 0: phase 1 of step s in [2s, 2s+1], MFMAs in [2s+1, 2s+2];
+  // group 1 one index later):  weight stage (s+1)&1 is read until 2s+1 (group 1's MFMAs of step s-1) and both groups
+  // issue its refill inside [2s+1, 2s+2]; the refill is waited for (counted vmcnt) before barrier 2s+2, after which
+  // group 0 reads it.  Halo image c+1 is written in phase 1 of taps 3..8 of chunk c and first read after two more
+  // barriers; its previous content was last read three steps before the first write.
+  wait_vmcnt0();
+  if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
+  if (wm == 0) __syncthreads();
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   wait_vmcnt0();
@@ -448,6 +476,9 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
       case 7: return launch_fused<__bf16, 7>(a, (hipStream_t)stream);
       case 8: return launch_fused<__bf16, 8>(a, (hipStream_t)stream);
       case 15: return launch_fused<__bf16, 15>(a, (hipStream_t)stream);
+      case 16: return launch_fused<__bf16, 16>(a, (hipStream_t)stream);
+      case 32: return launch_fused<__bf16, 32>(a, (hipStream_t)stream);
+      case 64: return launch_fused<__bf16, 64>(a, (hipStream_t)stream);
       default: break;
     }
   }

@@ -32,7 +32,11 @@ def main():
     shapes = [SHAPES[int(i)] for i in only.split(",")] if only else SHAPES
     for (h, cin, cout, taps) in shapes:
         x = torch.randn(n, h, h, cin, device="cuda").to(tdt)
+        if os.environ.get("ZERO") == "1":     # zero operands: no data toggling in the MFMA datapath (power / clock probe)
+            x.zero_()
         w = (torch.randn(cout, taps * cin, device="cuda") / (taps * cin) ** 0.5).to(tdt)
+        if os.environ.get("ZERO") == "1":
+            w.zero_()
         b = torch.randn(cout, device="cuda")
         out = torch.empty(n, h, h, cout, device="cuda", dtype=tdt)
         flop = 2.0 * n * h * h * cout * taps * cin
