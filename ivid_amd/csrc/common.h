@@ -62,8 +62,13 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // ds_read -> MFMA software pipeline of the conv kernels.  With the asm form the compiler counts its own LDS reads
 // exactly; the DMA itself is ordered by hand (wait_vmcnt0() + barrier before the stage is read, as before).  No other
 // code in these kernels uses M0.
-__device__ __forceinline__ unsigned lds_addr_of(const void* lds_ptr) {  // wave-uniform LDS byte address in an SGPR
-  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds_ptr);
+// Wave-uniform LDS byte address (SGPR) of a pointer into the dynamic LDS block.  Computed as an offset from the dynamic
+// LDS symbol -- a generic->LDS address-space cast would carry a null check (and trips a compiler bug in some
+// instantiations).  Every kernel here uses `extern __shared__` memory only.
+extern __shared__ __attribute__((aligned(16))) char ivid_dyn_lds[];
+__device__ __forceinline__ unsigned lds_addr_of(const void* lds_ptr) {
+  const unsigned off = (unsigned)((const char*)lds_ptr - (const char*)ivid_dyn_lds) + __builtin_amdgcn_groupstaticsize();
+  return __builtin_amdgcn_readfirstlane(off);
 }
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr_of(lds_wave_base)) : "memory");
@@ -71,6 +76,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // same with a wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit VALU address arithmetic
 __device__ __forceinline__ void glds16_s(const void* base, unsigned voff, void* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr_of(lds_wave_base)) : "memory");
+}
+
+// Ordering between LDS writes and reads of ONE wave (per-wave transpose slabs): the LDS executes a wave's instructions
+// in order, so no workgroup barrier is needed -- only the compiler must not reorder across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -86,6 +86,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BYTES;
 
+  unsigned long long ts[4];
+  if (AB & 256) ts[0] = wall_clock64();
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   // tile id -> (image, tile row, tile col, cout tile); cout tiles of one pixel tile are neighbours (shared A in L2)
   const int tn = tile % p.ntiles_n;
@@ -332,10 +334,12 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // group 0 reads it.  Halo image c+1 is written in phase 1 of taps 3..8 of chunk c and first read after two more
   // barriers; its previous content was last read three steps before the first write.
   wait_vmcnt0();
+  if (AB & 256) ts[1] = wall_clock64();
   if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
   if (wm == 0) __syncthreads();
+  if (AB & 256) ts[2] = wall_clock64();
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   wait_vmcnt0();
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
         slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
       }
-    __syncthreads();
+    wave_lds_sync();  // the slab is private to this wave
     const int y = y0 + wm * 4 + mi;                        // this fragment = image row y, pixels x0 .. x0+31
     const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;
     const int nbase = n0 + wn * WTN;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
         const vec_t ov = f32_to_vec<T>(v);
         *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
-        if (p.stats) {
+        if (p.stats && !(AB & 256)) {
           float sv[VE];
           vec_to_f32<T>(ov, sv);
 #pragma unroll
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
       }
     }
-    if (p.stats && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
+    if (p.stats && !(AB & 256) && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -422,7 +426,15 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
       }
     }
-    __syncthreads();
+    wave_lds_sync();  // the slab is private to this wave
+  }
+  if (AB & 256) {  // development: per-workgroup phase timestamps (100 MHz) + hardware id into the stats buffer
+    ts[3] = wall_clock64();
+    if (tid == 0) {
+      unsigned long long* o = (unsigned long long*)p.stats + (size_t)blockIdx.x * 5;
+      o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3];
+      o[4] = __smid();
+    }
   }
 }
 
@@ -479,6 +491,7 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
       case 16: return launch_fused<__bf16, 16>(a, (hipStream_t)stream);
       case 32: return launch_fused<__bf16, 32>(a, (hipStream_t)stream);
       case 64: return launch_fused<__bf16, 64>(a, (hipStream_t)stream);
+      case 256: return launch_fused<__bf16, 256>(a, (hipStream_t)stream);
       default: break;
     }
   }

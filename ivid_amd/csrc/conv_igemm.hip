@@ -267,7 +267,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
         slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
       }
-    __syncthreads();
+    wave_lds_sync();  // the slab is private to this wave
     const int mbase = m0 + wm * WTM + mi * 32;
     const int nbase = n0 + wn * WTN;
     if (p.out_mode == 0) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         }
       }
     }
-    __syncthreads();
+    wave_lds_sync();  // the slab is private to this wave
   }
 }
 
