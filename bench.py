@@ -44,9 +44,33 @@ def fused_flops(args):
     return 2.0 * n * h * w * cout * 9 * (c0 + c1)
 
 
+def conv_bytes(args, fused):
+    """Algorithmic HBM bytes of one convolution launch: every input element, weight and residual read once, every output
+    written once (compulsory traffic; the PMC-measured figure is reported beside it as `traffic`)."""
+    if fused:
+        (dtype, _s0, c0, _s1, c1, _ab, up, _w, _b, _o, r, rm, n, h, w, cout, _st) = args
+        taps, om = 9, 0
+    else:
+        (dtype, _s0, c0, _s1, c1, _w, _b, _o, r, rm, om, n, h, w, cout, taps, _tc, _st) = args
+        up = 0
+    esz = 2 if dtype == 1 else 4
+    src = n * (h >> up) * (w >> up) * (c0 + c1) * esz
+    out = n * h * w * cout * (4 if om else esz)
+    res = 0 if not rm else (out if rm == 1 else (out // 4 if rm == 2 else out * 4))
+    return float(src + out + res + cout * taps * (c0 + c1) * esz)
+
+
 def attn_flops(args):
     (_dtype, _q, _o, n, t, heads) = args
     return 2.0 * (2.0 * heads * t * t * 64) * n
+
+
+def pmc_traffic():
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        return round(float(json.load(open(f))["conv_family_hbm_bytes_per_launch"]), 0)
+    except Exception:
+        return None
 
 
 def main():
@@ -148,29 +172,34 @@ def main():
         prof = plan.profile_eager()
         fam = {}
         for name, args, ms in prof:
-            f = fam.setdefault(name, dict(ms=0.0, n=0, flop=0.0))
+            f = fam.setdefault(name, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
             f["ms"] += ms
             f["n"] += 1
             if name == "ivid_conv2d":
                 fl, dt_ = conv_flops(args)
                 if dt_ == (1 if a.precision == "bf16" else 0):
                     f["flop"] += fl
+                f["byt"] += conv_bytes(args, False)
             elif name == "ivid_conv3x3_gn":
                 f["flop"] += fused_flops(args)
+                f["byt"] += conv_bytes(args, True)
             elif name == "ivid_attention":
                 f["flop"] += attn_flops(args)
         total_ms = sum(f["ms"] for f in fam.values())
         conv = dict(fam["ivid_conv2d"])
         if "ivid_conv3x3_gn" in fam:  # the two MFMA convolution kernels together = 97 % of the model's FLOPs
-            for k in ("ms", "n", "flop"):
+            for k in ("ms", "n", "flop", "byt"):
                 conv[k] += fam["ivid_conv3x3_gn"][k]
         ach = conv["flop"] / (conv["ms"] * 1e-3) / 1e12
         result["roofline"] = {
             "kernel": "conv3x3_fused_kernel + conv_igemm_kernel (all %d convolution launches of one batch-%d forward)" % (conv["n"], plan.n),
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": None,
+            # HBM bytes per conv-family launch from the PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE, gfx950-corrected; scripts/gpu_pmc_bench.sh -> profiles/pmc_traffic.json); null if not collected
+            "traffic": pmc_traffic(),
             "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
             "algorithmic_gflop_per_launch_avg": round(conv["flop"] / conv["n"] / 1e9, 2),
+            "algorithmic_bytes_per_launch_avg": round(conv["byt"] / conv["n"], 0),
             "share_of_forward_time": round(conv["ms"] / total_ms, 4),
         }
         result["kernel_time_ms_per_forward"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items())}
