@@ -39,16 +39,19 @@ def conv_flops(args):
 
 
 def fused_flops(args):
-    """Algorithmic FLOPs of one ivid_conv3x3_gn launch (2 x MACs; the GroupNorm/SiLU prologue counts 0)."""
-    (_dtype, _s0, c0, _s1, c1, _ab, _up, _w, _b, _o, _r, _rm, n, h, w, cout, _st) = args
-    return 2.0 * n * h * w * cout * 9 * (c0 + c1)
+    """Algorithmic FLOPs of one ivid_conv3x3_gn[_skip] launch (2 x MACs; the GroupNorm/SiLU prologue counts 0)."""
+    (_dtype, _s0, c0, _s1, c1, _ab, _up, _w, _b, _o, _r, _rm, n, h, w, cout, _st) = args[:17]
+    skc = (args[18] + args[20]) if len(args) > 17 else 0      # 1x1 skip_connection folded into the kernel
+    return 2.0 * n * h * w * cout * (9 * (c0 + c1) + skc)
 
 
 def conv_bytes(args, fused):
     """Algorithmic HBM bytes of one convolution launch: every input element, weight and residual read once, every output
     written once (compulsory traffic; the PMC-measured figure is reported beside it as `traffic`)."""
+    skc = 0
     if fused:
-        (dtype, _s0, c0, _s1, c1, _ab, up, _w, _b, _o, r, rm, n, h, w, cout, _st) = args
+        (dtype, _s0, c0, _s1, c1, _ab, up, _w, _b, _o, r, rm, n, h, w, cout, _st) = args[:17]
+        skc = (args[18] + args[20]) if len(args) > 17 else 0
         taps, om = 9, 0
     else:
         (dtype, _s0, c0, _s1, c1, _w, _b, _o, r, rm, om, n, h, w, cout, taps, _tc, _st) = args
@@ -57,7 +60,7 @@ def conv_bytes(args, fused):
     src = n * (h >> up) * (w >> up) * (c0 + c1) * esz
     out = n * h * w * cout * (4 if om else esz)
     res = 0 if not rm else (out if rm == 1 else (out // 4 if rm == 2 else out * 4))
-    return float(src + out + res + cout * taps * (c0 + c1) * esz)
+    return float(src + out + res + cout * taps * (c0 + c1) * esz + n * h * w * skc * esz + cout * skc * esz)
 
 
 def attn_flops(args):
@@ -172,7 +175,8 @@ def main():
         prof = plan.profile_eager()
         fam = {}
         for name, args, ms in prof:
-            f = fam.setdefault(name, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
+            fused = name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip")
+            f = fam.setdefault("ivid_conv3x3_gn" if fused else name, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
             f["ms"] += ms
             f["n"] += 1
             if name == "ivid_conv2d":
@@ -180,7 +184,7 @@ def main():
                 if dt_ == (1 if a.precision == "bf16" else 0):
                     f["flop"] += fl
                 f["byt"] += conv_bytes(args, False)
-            elif name == "ivid_conv3x3_gn":
+            elif fused:
                 f["flop"] += fused_flops(args)
                 f["byt"] += conv_bytes(args, True)
             elif name == "ivid_attention":
@@ -210,7 +214,7 @@ def main():
                     fl, _ = conv_flops(args)
                     rows.append(dict(n=args[11], h=args[12], cin=args[2] + args[4], cout=args[14], taps=args[15],
                                      res=args[9], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
-                elif name == "ivid_conv3x3_gn":
+                elif name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip"):
                     fl = fused_flops(args)
                     rows.append(dict(fused=1, n=args[12], h=args[13], cin=args[2] + args[4], cout=args[15], taps=9, up=args[6],
                                      res=args[11], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))

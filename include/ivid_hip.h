@@ -70,6 +70,14 @@ int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg);
 int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                     const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
                     int Cout, float* stats, void* stream);
+/* Same, plus the ResBlock's 1x1 `skip_connection` (adm.py:190, `self.skip_connection(x) + h`, adm.py:222) accumulated
+ * into the same output tile: out = conv3x3(silu(gn(src))) + conv1x1(cat(skip0, skip1)) + bias (+ res).
+ *   skip0/skip1  NHWC [N,H,W,skipC0 / skipC1] (the block's raw input, e.g. the decoder's cat([h, hs.pop()])); skip_weight
+ *   [Cout][skipC0+skipC1] in the compute dtype; `bias` must already hold conv bias + skip bias.  skipC0 = 0 disables it. */
+int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                         const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H,
+                         int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
+                         const void* skip_weight, void* stream);
 
 /* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
  * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).

@@ -43,6 +43,11 @@ struct FusedArgs {
   int up;              // 0: source has the output size; 1: nearest x2 upsample of the activated source
   int res_mode;        // 0 none, 1 same, 2 residual source is (H/2, W/2) nearest-up
   int tiles_x, tiles_y, ntiles_n, ntiles_total;
+  // optional 1x1 skip convolution of the ResBlock input accumulated into the same tile (adm.py:190,222)
+  const char* sk0;
+  const char* sk1;
+  const char* skw;     // [Cout][skC0+skC1]
+  int skC0, skC1;
 };
 
 template <typename T> struct Mma2;
@@ -338,7 +343,69 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
-  if (wm == 0) __syncthreads();
+  if (wm == 0) __syncthreads();  // the two wave groups are aligned again
+
+  // ---------------- optional skip phase: acc += x[tile pixels] . Wskip  (the ResBlock's 1x1 skip_connection on its raw
+  // input x = cat(sk0, sk1)); a plain 2-stage LDS-DMA pipeline like conv_igemm with taps = 1: A stage = the tile's 256
+  // pixels x 128 B (swizzled) inside the now idle halo region, B stage as before ----------------
+  if (p.skC0 > 0) {
+    const int sk_ctot = p.skC0 + p.skC1;
+    const int sk_chunks = sk_ctot / BKE;
+    const int r0 = tid >> 3;                                  // stage row of piece i: 64 i + r0 (same swizzle for all i)
+    const int swz = ((tid & 7) ^ ((r0 >> 1) & 7)) << 4;
+    const size_t sk_px = (size_t)img * p.H * p.W;
+    const char* const sk0_img = p.sk0 + sk_px * p.skC0 * sizeof(T);
+    const char* const sk1_img = p.sk1 + sk_px * p.skC1 * sizeof(T);
+    int spix[4];
+    unsigned sb_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 64 * i + r0;                            // tile pixel: image row y0 + row/32, column x0 + row%32
+      spix[i] = (y0 + (row >> 5)) * p.W + x0 + (row & 31);
+      const int wrow = min(n0 + row, p.Cout - 1);
+      sb_voff[i] = (unsigned)((size_t)wrow * sk_ctot * sizeof(T)) + swz;
+    }
+    auto issue_skip = [&](int stage, int c) {
+      const int cbase = c * BKE;
+      const bool second = cbase >= p.skC0;
+      const char* abase = second ? sk1_img + (size_t)(cbase - p.skC0) * sizeof(T) : sk0_img + (size_t)cbase * sizeof(T);
+      const int cb = (second ? p.skC1 : p.skC0) * (int)sizeof(T);
+      const char* wbase = p.skw + (size_t)cbase * sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        glds16_s(abase, __umul24(spix[i], cb) + swz, sA0 + stage * 32768 + (i * NT + wave * 64) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16_s(wbase, sb_voff[i], sB0 + stage * B_BYTES + (i * NT + wave * 64) * 16);
+    };
+    const int sa_addr0 = (wm * 128 + frow) * 128 + ((fhalf ^ (((wm * 128 + frow) >> 1) & 7)) << 4);
+    issue_skip(0, 0);
+    for (int c = 0; c < sk_chunks; ++c) {
+      wait_vmcnt0();
+      __syncthreads();  // stage c&1 landed for every wave; everyone finished reading the other stage
+      if (c + 1 < sk_chunks) issue_skip((c + 1) & 1, c + 1);
+      const int a_off = (c & 1) * 32768 + sa_addr0;
+      const int b_off = (c & 1) * B_BYTES + b_addr0;
+      vec_t a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA0 + a_off + mi * 4096);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int xo = (kk + 1) << 5;
+        const bool pf = kk < 3;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) Mma2<T>::run(a[mi], b[0], acc[mi][0]);
+        if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          Mma2<T>::run(a[mi], b[1], acc[mi][1]);
+          if (pf) a[mi] = *(const vec_t*)(sA0 + (a_off ^ xo) + mi * 4096);
+        }
+        if (pf) b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
+      }
+    }
+  }
   if (AB & 256) ts[2] = wall_clock64();
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
@@ -452,9 +519,10 @@ template <typename T, int AB = 0> int launch_fused(const FusedArgs& a, hipStream
 
 }  // namespace
 
-extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
-                               const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
-                               int H, int W, int Cout, float* stats, void* stream) {
+extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                                    const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
+                                    int H, int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1,
+                                    int skipC1, const void* skip_weight, void* stream) {
   const int esz = dtype == IVID_F32 ? 4 : 2;
   const int bke = 128 / esz, ve = 16 / esz;
   if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
@@ -465,9 +533,14 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
   if (up && ((H | W) & 1)) return ivid_set_error("conv3x3_gn: upsample needs even H,W", hipSuccess);
   if (res_mode < 0 || res_mode > 2 || (res_mode && !res)) return ivid_set_error("conv3x3_gn: bad residual", hipSuccess);
   if (!ab) return ivid_set_error("conv3x3_gn: ab missing", hipSuccess);
+  if (skipC0 < 0 || skipC1 < 0 || skipC0 % bke || skipC1 % bke || (skipC0 == 0 && skipC1 > 0))
+    return ivid_set_error("conv3x3_gn: skip channels must be multiples of the K-step", hipSuccess);
+  if (skipC0 > 0 && (!skip0 || !skip_weight || (skipC1 > 0 && !skip1)))
+    return ivid_set_error("conv3x3_gn: skip source / weight missing", hipSuccess);
   {  // the kernel addresses one image / the weight matrix with 32-bit byte offsets from a 64-bit wave-uniform base
-    const size_t hs = up ? H / 2 : H, ws = up ? W / 2 : W, cmax = C0 > C1 ? C0 : C1;
-    if (hs * ws * cmax * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * (C0 + C1) * esz >= ((size_t)1 << 32))
+    const size_t hs = up ? H / 2 : H, ws = up ? W / 2 : W, cmax = C0 > C1 ? C0 : C1, smax = skipC0 > skipC1 ? skipC0 : skipC1;
+    if (hs * ws * cmax * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * (C0 + C1) * esz >= ((size_t)1 << 32) ||
+        (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
   FusedArgs a;
@@ -477,19 +550,15 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.up = up ? 1 : 0; a.res_mode = res_mode;
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
+  a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
 #ifdef IVID_DEV_ABLATE
   if (dtype == IVID_BF16) {
     static const int ablate = getenv("IVID_FUSED_ABLATE") ? atoi(getenv("IVID_FUSED_ABLATE")) : 0;
     switch (ablate) {
       case 1: return launch_fused<__bf16, 1>(a, (hipStream_t)stream);
       case 2: return launch_fused<__bf16, 2>(a, (hipStream_t)stream);
-      case 3: return launch_fused<__bf16, 3>(a, (hipStream_t)stream);
       case 4: return launch_fused<__bf16, 4>(a, (hipStream_t)stream);
-      case 7: return launch_fused<__bf16, 7>(a, (hipStream_t)stream);
       case 8: return launch_fused<__bf16, 8>(a, (hipStream_t)stream);
-      case 15: return launch_fused<__bf16, 15>(a, (hipStream_t)stream);
-      case 16: return launch_fused<__bf16, 16>(a, (hipStream_t)stream);
-      case 32: return launch_fused<__bf16, 32>(a, (hipStream_t)stream);
       case 64: return launch_fused<__bf16, 64>(a, (hipStream_t)stream);
       case 256: return launch_fused<__bf16, 256>(a, (hipStream_t)stream);
       default: break;
@@ -498,4 +567,11 @@ extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* 
 #endif
   if (dtype == IVID_BF16) return launch_fused<__bf16>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                               const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
+                               int H, int W, int Cout, float* stats, void* stream) {
+  return ivid_conv3x3_gn_skip(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats,
+                              nullptr, 0, nullptr, 0, nullptr, stream);
 }

@@ -129,6 +129,8 @@ class UNetPlan:
         self.debug = debug      # eager-only: snapshot every op's output (NCHW fp32) into self.taps
         self.fuse_stats = os.environ.get("IVID_NO_FUSED_STATS", "0") != "1"   # GN partials from conv epilogues
         self.fuse_conv = os.environ.get("IVID_NO_FUSED_CONV", "0") != "1"     # GN-apply+SiLU inside the 3x3 conv (W >= 32)
+        self.fuse_skip = os.environ.get("IVID_NO_FUSED_SKIP", "0") != "1"     # 1x1 skip_connection inside that kernel too
+        self._sum_bias = {}
         self.taps = {}
         self.dtype = weights.dtype
         self.esz = 4 if self.dtype == _lib.F32 else 2
@@ -232,13 +234,25 @@ class UNetPlan:
         self.arena.put(ab)
         return y
 
-    def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode):
-        """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip)."""
+    def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode, skip=None):
+        """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip).  skip = (s0, s1, wname): the
+        ResBlock's 1x1 skip_connection on its raw input cat(s0, s1), accumulated in the same kernel."""
         out.stats_blk = 128
-        self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
+        st = out.stats.data_ptr() if out.stats is not None else None
+        if skip is None:
+            self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
+                      x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
+                      self.w[wname + ".bias"].data_ptr(), out.ptr, res_ptr, res_mode, out.n, out.side, out.side, out.c, st)
+            return
+        s0, s1, sname = skip
+        key = wname + "+" + sname
+        if key not in self._sum_bias:   # conv bias + skip bias, added once in the epilogue
+            self._sum_bias[key] = (self.w[wname + ".bias"] + self.w[sname + ".bias"]).contiguous()
+        self._rec("ivid_conv3x3_gn_skip", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
                   x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
-                  self.w[wname + ".bias"].data_ptr(), out.ptr, res_ptr, res_mode, out.n, out.side, out.side, out.c,
-                  out.stats.data_ptr() if out.stats is not None else None)
+                  self._sum_bias[key].data_ptr(), out.ptr, res_ptr, res_mode, out.n, out.side, out.side, out.c, st,
+                  s0.ptr, s0.c, s1.ptr if s1 is not None else None, s1.c if s1 is not None else 0,
+                  self.w[sname + ".weight"].data_ptr())
 
     # ---- ops ----
     def _res(self, op: Res, x: _Act, skip):
@@ -262,6 +276,17 @@ class UNetPlan:
             act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
             self._free(h1)
         out = self._new(n, so, op.cout, stats=True)
+        kstep = 128 // self.esz
+        if (fused and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
+                and (skip is None or skip.c % kstep == 0)):
+            # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
+            # residual round trip)
+            assert op.mode == "same"
+            self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, None, 0,
+                           skip=(x, skip, op.prefix + ".skip_connection"))
+            self.arena.put(ab2)
+            self._free(h1)
+            return out
         if op.has_skip_conv:
             assert op.mode == "same"
             r = self._new(n, so, op.cout)

@@ -171,6 +171,55 @@ def test_conv3x3_gn_fused(case, dtype):
     assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
 
 
+SKIP_CASES = [
+    # name, N, H, W, C (conv input), Cout, skipC0, skipC1
+    ("skip_cat_128+64_to_64", 2, 16, 32, 64, 64, 128, 64),
+    ("skip_single_256_to_320_ntiles2", 1, 8, 64, 128, 320, 256, 0),
+    ("skip_cat_64+192_cout_tail_72", 1, 8, 32, 64, 72, 64, 192),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", SKIP_CASES, ids=[c[0] for c in SKIP_CASES])
+def test_conv3x3_gn_fused_with_skip_conv(case, dtype):
+    """out_layers conv + the ResBlock's 1x1 skip_connection on the raw block input in ONE kernel (adm.py:190,214-222)."""
+    name, N, H, W, Cc, Cout, S0, S1 = case
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    h = common.seeded_randn(s, N, Cc, H, W)
+    a = 0.5 + 0.5 * torch.rand(N, Cc, generator=torch.Generator().manual_seed(s))
+    b = 0.3 * common.seeded_randn(s + 2, N, Cc)
+    w = common.seeded_randn(s + 3, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    x0 = common.seeded_randn(s + 6, N, S0, H, W)
+    x1 = common.seeded_randn(s + 7, N, S1, H, W) if S1 else None
+    wsk = common.seeded_randn(s + 8, Cout, S0 + S1, 1, 1) / np.sqrt(S0 + S1)
+    bias = common.seeded_randn(s + 4, Cout) * 0.1          # conv bias + skip bias, combined by the caller
+    act = G.rounded(F.silu(G.rounded(h, dtype) * a[:, :, None, None] + b[:, :, None, None]), dtype)
+    xs = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    ref = (F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1)
+           + F.conv2d(xs.double(), G.rounded(wsk, dtype).double())).float()
+    dh = G.to_nhwc(h, dtype)
+    d0 = G.to_nhwc(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    wsp = wsk.reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    bd = bias.cuda()
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
+    L.call("ivid_conv3x3_gn_skip", dtype, L.ptr(dh), Cc, None, 0, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out), None, 0,
+           N, H, W, Cout, L.ptr(stats), L.ptr(d0), S0, L.ptr(d1), S1, L.ptr(wsp), G.stream())
+    torch.cuda.synchronize()
+    got = G.from_nhwc(out)
+    e = common.rel_l2(got, ref)
+    G.report(f"conv3x3_gn_skip/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
+    o = out.float().reshape(N, H // 4, 4, W // 32, 32, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 128, Cout)
+    sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
+
+
 def test_conv2d_is_transpose_detecting_identity_weights():
     # A = asymmetric ramp, W = identity 1x1: out must equal in exactly (catches swapped C/D row/col maps)
     N, H, W, Cc = 1, 16, 16, 128
