@@ -163,7 +163,11 @@ int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const f
  * Step 1, per generated view: depth -> textured grid mesh with frustum skirt (rgbd_3d/utils.py:144-260
  * depth_to_mesh(padding='frustum', cal_normal=True), linearize_depth :38-58, unproject :89-110,
  * triangulate :113-134, mask_discontinuity :137-141, cal_depth_normal :263-274), batched over B samples.
- *   rgbd          : fp32 [B,4,S,S] network output in [-1,1] (RGB + z-buffer depth, inference/sample.py:83,126)
+ *   rgbd          : fp32 [B,4,S,S]; input_mode 0: network output in [-1,1] (RGB + z-buffer depth encoded with nearv/farv,
+ *                   inference/sample.py:83,126); input_mode 1: a stored scene — RGB in [0,1] and METRIC depth
+ *                   (load_scene, inference/utils.py:103-113)
+ *   padding       : < 0: padding='frustum' (the sampling driver, sample.py:129-133); >= 0: numeric padding in pixels
+ *                   (load_scene uses 32, utils.py:201-205)
  *   inv_modelview : fp32 [B][16] row-major camera->world matrix (glm.inverse(modelview), utils.py:232-237)
  *   verts         : out fp32 [B][(S+2)^2][9] = world position(3), world normal(3), uv(2), flag(1) with
  *                   flag = 1*discontinuity + 2*padding + 4*eroded (utils.py:249) — the reference's VBO layout
@@ -172,8 +176,8 @@ int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const f
  *   colors        : out fp32 [B][S][S][3] RGB in [0,1] (the NEAREST texture, moderngl_renderer.py:293)
  *   scratch_depth : fp32 [B][(S+2)^2]; scratch_flags: int32 [B][(S+2)^2] */
 int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview, float fov_deg, float nearv,
-                    float farv, float atol, float rtol, int erode, float* verts, unsigned char* diag, float* colors,
-                    float* scratch_depth, int* scratch_flags, void* stream);
+                    float farv, float atol, float rtol, int erode, float padding, int input_mode, float* verts,
+                    unsigned char* diag, float* colors, float* scratch_depth, int* scratch_flags, void* stream);
 /* Step 2, per target view: z-buffered rasterisation of every source-view mesh ALONE (depth test '<', no cull,
  * moderngl_renderer.py:198-202,307-312; aggregation.vsh/.fsh) + weighted aggregation across source views
  * (clear.csh, aggregation.csh) + the read-back math of AggregationRenderer.render (:317-331), image row 0 = top.

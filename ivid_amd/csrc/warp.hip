@@ -32,11 +32,15 @@ struct MeshParams {
   float nearv, farv;        // z-buffer encoding of the network's depth channel (CLI near/far)
   float atol, rtol;
   int erode;
+  int frustum;              // 1: padding='frustum' (sample.py), 0: numeric padding of `padpx` pixels (load_scene, render.py)
+  double padpx;
+  int metric;               // 1: input holds RGB in [0,1] and METRIC depth (a stored scene), 0: network output in [-1,1]
 };
 
 // linear (metric) depth of pixel (r,c) in fp32, as inference/sample.py:83,126 + linearize_depth do
 __device__ __forceinline__ float lin_depth(const float* rgbd, const MeshParams& m, int b, int r, int c) {
   const int S = m.S;
+  if (m.metric) return rgbd[((size_t)b * 4 + 3) * S * S + (size_t)r * S + c];
   // every operation rounded separately like numpy's float32 arithmetic (no FMA contraction): neighbouring depths
   // differ by ~1e-3, so a 1-ulp change here shows up as 1e-5 in the normals
   float d = __fadd_rn(__fmul_rn(rgbd[((size_t)b * 4 + 3) * S * S + (size_t)r * S + c], 0.5f), 0.5f);
@@ -67,11 +71,12 @@ __device__ __forceinline__ D3 pad_point(const float* rgbd, const MeshParams& m, 
   D3 p = cam_point(rgbd, m, b, pr - 1, pc - 1);
   const double d = -p.z;
   const bool top = pr == 0, bot = pr == P - 1, lef = pc == 0, rig = pc == P - 1;
-  if (top) p.y += m.ppp * d;
-  if (bot) p.y -= m.ppp * d;
-  if (lef) p.x -= m.ppp * d;
-  if (rig) p.x += m.ppp * d;
-  if (top || bot || lef || rig) p = mul(p, -0.1 / p.z);
+  const double ppp = m.frustum ? m.ppp : m.padpx * m.ppp;  // utils.py:186 / :201
+  if (top) p.y += ppp * d;
+  if (bot) p.y -= ppp * d;
+  if (lef) p.x -= ppp * d;
+  if (rig) p.x += ppp * d;
+  if (m.frustum && (top || bot || lef || rig)) p = mul(p, -0.1 / p.z);
   return p;
 }
 
@@ -111,7 +116,9 @@ __global__ __launch_bounds__(256) void mesh_points_kernel(const float* __restric
     const size_t px = (size_t)(pr - 1) * S + (pc - 1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-      colors[((size_t)b * S * S + px) * 3 + ch] = __fadd_rn(__fmul_rn(rgbd[((size_t)b * 4 + ch) * S * S + px], 0.5f), 0.5f);
+      colors[((size_t)b * S * S + px) * 3 + ch] =
+          m.metric ? rgbd[((size_t)b * 4 + ch) * S * S + px]
+                   : __fadd_rn(__fmul_rn(rgbd[((size_t)b * 4 + ch) * S * S + px], 0.5f), 0.5f);
   }
 }
 
@@ -484,15 +491,17 @@ __global__ __launch_bounds__(256) void cond_final_kernel(const unsigned char* __
 }  // namespace
 
 extern "C" int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview, float fov_deg, float nearv,
-                               float farv, float atol, float rtol, int erode, float* verts, unsigned char* diag,
-                               float* colors, float* scratch_depth, int* scratch_flags, void* stream) {
+                               float farv, float atol, float rtol, int erode, float padding, int input_mode, float* verts,
+                               unsigned char* diag, float* colors, float* scratch_depth, int* scratch_flags, void* stream) {
   if (B <= 0 || S < 2) return ivid_set_error("mesh_build: bad size", hipSuccess);
+  if (input_mode != 0 && input_mode != 1) return ivid_set_error("mesh_build: bad input_mode", hipSuccess);
   MeshParams m;
   m.B = B; m.S = S; m.P = S + 2;
   const double fov = (double)fov_deg * 3.14159265358979323846 / 180.0;
   m.focal = 0.5 / tan(0.5 * fov);
   m.ppp = 2.0 * tan(0.5 * fov) / S;
   m.nearv = nearv; m.farv = farv; m.atol = atol; m.rtol = rtol; m.erode = erode;
+  m.frustum = padding < 0.f ? 1 : 0; m.padpx = padding; m.metric = input_mode;
   hipStream_t s = (hipStream_t)stream;
   const int PP = m.P * m.P, QQ = (m.P - 1) * (m.P - 1);
   hipLaunchKernelGGL(mesh_points_kernel, dim3((PP + 255) / 256, B), dim3(256), 0, s, rgbd, m, inv_modelview, verts,

@@ -18,7 +18,7 @@ import torch
 from .. import parallel, rgbd_3d
 from ..diffusion import backbones, frameworks, samplers
 from ..utils import AttrDict
-from .utils import parse_int_list, reorder, save_grid, save_png
+from .utils import colorize_depth, parse_int_list, reorder, save_grid, save_png, save_scene
 
 
 @torch.no_grad()
@@ -91,9 +91,10 @@ def sample_all(framework_uncond, framework_cond, seeds_or_num_samples, steps_unc
             yield samples[j], ({k: v[j] for k, v in cstack.items()} if cstack is not None else None)
 
 
-def async_save(samples, conds, suffix, cfg):
-    """Writer thread with the reference's retry-and-swallow behaviour (sample.py:150-176).  Tensors are complete: the
-    caller synchronises before handing them over."""
+def async_save(samples, conds, suffix, cfg, modelviews):
+    """Writer thread with the reference's retry-and-swallow behaviour and output tree (sample.py:150-176): results/,
+    grids/ (rgb + inferno depth, 3x9 order), conds/ and scenes/*.npz in the reference's scene wire format.  Tensors are
+    complete: the caller synchronises before handing them over."""
     samples = samples.cpu()
     conds = {k: v.cpu() for k, v in conds.items()} if conds is not None else None
 
@@ -101,17 +102,22 @@ def async_save(samples, conds, suffix, cfg):
         for _ in range(10):
             try:
                 out = cfg.output_dir
+                scene = os.path.join(out, "scenes", f"scene_{suffix}.npz")
                 if cfg.viewset == "uncond":
                     save_png(os.path.join(out, "results", f"rgb_{suffix}.png"), samples[0, :3])
+                    save_scene(scene, samples, modelviews, cfg.fov, cfg.near, cfg.far)
                 elif cfg.viewset == "random":
                     save_grid(os.path.join(out, "grids", f"rgb_{suffix}.png"), samples[:, :3], 2)
                     save_png(os.path.join(out, "conds", f"rgb_{suffix}.png"), samples[0, :3])
                     save_png(os.path.join(out, "results", f"rgb_{suffix}.png"), samples[1, :3])
                 else:
                     save_grid(os.path.join(out, "grids", f"rgb_{suffix}.png"), reorder(samples[:, :3], cfg.viewset), 9)
-                    save_grid(os.path.join(out, "grids", f"depth_{suffix}.png"), reorder(samples[:, 3:].repeat(1, 3, 1, 1), cfg.viewset), 9)
+                    save_grid(os.path.join(out, "grids", f"depth_{suffix}.png"),
+                              reorder(colorize_depth(samples[:, 3:]), cfg.viewset), 9)
                     save_grid(os.path.join(out, "conds", f"rgb_cond_{suffix}.png"), reorder(conds["color"][:, :3], cfg.viewset), 9)
-                np.savez_compressed(os.path.join(out, "scenes", f"scene_{suffix}.npz"), rgbd=samples.numpy())
+                    save_grid(os.path.join(out, "conds", f"depth_cond_{suffix}.png"),
+                              reorder(colorize_depth(conds["depth"]), cfg.viewset), 9)
+                    save_scene(scene, samples, modelviews, cfg.fov, cfg.near, cfg.far)
                 break
             except Exception as e:  # noqa: BLE001
                 print(e)
@@ -206,7 +212,8 @@ def main(argv=None):
             parts.append(f"class{classes_r[i]:03d}")
         parts.append(f"seed{seeds_r[i]:05d}" if seeds_r is not None else f"{idx[i]:05d}")
         torch.cuda.synchronize(device)
-        threads.append(async_save(samples, conds, "_".join(parts), cfg))
+        mv_i = views_r[i] if isinstance(views_r[0], list) else views_r
+        threads.append(async_save(samples, conds, "_".join(parts), cfg, mv_i))
     for t in threads:
         t.join()
 

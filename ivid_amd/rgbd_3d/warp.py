@@ -67,8 +67,11 @@ class WarpRenderer:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     @torch.no_grad()
-    def add_view(self, rgbd, modelview, fov=45.0, near=0.6, far=5.0, atol=0.03, rtol=0.03, erode_rgb=3):
-        """Append the meshes of a newly generated view: rgbd [B,4,S,S] network output in [-1,1] (device)."""
+    def add_view(self, rgbd, modelview, fov=45.0, near=0.6, far=5.0, atol=0.03, rtol=0.03, erode_rgb=3, padding="frustum",
+                 metric=False):
+        """Append the meshes of a view.  Default: rgbd [B,4,S,S] is the network output in [-1,1] (device) and the mesh
+        gets the frustum skirt (sample.py:129-133).  metric=True: rgbd holds RGB in [0,1] and METRIC depth (a stored
+        scene); padding = a number of pixels gives load_scene's numeric skirt (inference/utils.py:108-111)."""
         v = self.num_views
         if v >= self.max_views:
             raise _lib.IvidHipError(f"WarpRenderer holds at most {self.max_views} views")
@@ -78,10 +81,11 @@ class WarpRenderer:
         inv = np.stack([camera.inverse(m) for m in mv])
         inv_d = torch.from_numpy(inv.reshape(self.B, 16)).to(self.device)
         self.campos[v].copy_(torch.from_numpy(np.ascontiguousarray(inv[:, :3, 3])))
+        pad = -1.0 if padding == "frustum" else float(padding)
         _lib.call("ivid_mesh_build", _lib.ptr(rgbd), self.B, self.S, _lib.ptr(inv_d), float(fov), float(near), float(far),
                   float(atol if atol is not None else 0.0), float(rtol if rtol is not None else 0.0),
-                  int(erode_rgb or 0), _lib.ptr(self.verts[v]), _lib.ptr(self.diag[v]), _lib.ptr(self.colors[v]),
-                  _lib.ptr(self.scratch_depth), _lib.ptr(self.scratch_flags), self._stream())
+                  int(erode_rgb or 0), pad, 1 if metric else 0, _lib.ptr(self.verts[v]), _lib.ptr(self.diag[v]),
+                  _lib.ptr(self.colors[v]), _lib.ptr(self.scratch_depth), _lib.ptr(self.scratch_flags), self._stream())
         self.modelviews.append(mv)
         self.num_views += 1
 

@@ -78,6 +78,11 @@ for S, seed, yaw, pitch in [(16, 0, 0.0, 0.0), (32, 1, 0.3, -0.15)]:
     dproj = ref.project_depth(depth_lin.astype(np.float32), 0.6, 5.0)
     edge = ref.depth_edge(dproj, atol=0.03, rtol=0.03)
     assert np.array_equal(edge, W.depth_edge(dproj, 0.03, 0.03))
+    # the mesh load_scene rebuilds from a stored scene (inference/utils.py:108-111: numeric padding 32, metric depth)
+    mesh32 = ref.depth_to_mesh(depth_lin.astype(np.float32), 32, 45, mv, atol=0.03, rtol=0.03, erode_rgb=3, cal_normal=True)
+    out[f"vbo_pad32_{S}"] = np.concatenate([mesh32.vertices.position, mesh32.vertices.normal, mesh32.vertices.uv,
+                                            mesh32.vertices.flag], -1).astype(np.float32)
+    out[f"faces_pad32_{S}"] = mesh32.faces.astype(np.int32)
     out[f"rgbd_{S}"] = rgbd
     out[f"modelview_{S}"] = mv
     out[f"vbo_{S}"] = vb

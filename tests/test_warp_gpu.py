@@ -36,6 +36,48 @@ def test_mesh_build_matches_reference_fixture():
         assert np.array_equal(col, g[f"rgbd_{S}"][0, :3].transpose(1, 2, 0) * 0.5 + 0.5)
 
 
+def test_mesh_build_scene_mode_matches_reference_fixture():
+    """load_scene's mesh: metric depth in, numeric padding 32 (inference/utils.py:108-111) vs the live reference's
+    depth_to_mesh(depth, 32, ...) output (tests/golden/make_golden_warp.py)."""
+    g = C.load_golden("warp_mesh")
+    for S in (16, 32):
+        r = renderer(1, S)
+        rgbd = np.concatenate([g[f"rgbd_{S}"][0, :3] * 0.5 + 0.5, g[f"depth_lin_{S}"].astype(np.float32).transpose(2, 0, 1)], 0)
+        r.add_view(torch.from_numpy(rgbd[None].astype(np.float32)).cuda(), g[f"modelview_{S}"], 45, atol=0.03, rtol=0.03,
+                   erode_rgb=3, padding=32, metric=True)
+        m = r.mesh_numpy(0, 0)
+        vb = g[f"vbo_pad32_{S}"]
+        assert np.array_equal(m.faces, g[f"faces_pad32_{S}"])
+        assert np.array_equal(m.vertices.flag[:, 0], vb[:, 8])
+        e_pos = np.abs(m.vertices.position - vb[:, 0:3]).max()
+        e_nrm = np.abs(m.vertices.normal - vb[:, 3:6]).max()
+        G.report(f"warp/mesh_pad32_S{S}", pos=e_pos, normal=e_nrm)
+        assert e_pos < 4e-5 and e_nrm < 5e-5, (e_pos, e_nrm)   # the numeric skirt reaches |x| ~ 30: 1 fp32 ulp = 2e-6
+
+
+def test_scene_file_round_trip_and_free_view_render(tmp_path):
+    """save_scene -> load_scene -> meshes rebuilt on the GPU -> SSAA-5 free-view frames (inference/render.py:62-84).  The
+    frame rendered from a source camera must reproduce that source view."""
+    from ivid_amd.inference import render as R, utils as U
+    from ivid_amd.rgbd_3d import WarpRenderer
+    S = 64
+    mvs = [WC.orbit(0.0, 0.0), WC.orbit(0.2, 0.05)]
+    views = torch.from_numpy(np.concatenate([WC.synthetic_rgbd(S, 3, smooth_color=True), WC.synthetic_rgbd(S, 3, smooth_color=True)]))
+    path = str(tmp_path / "scenes" / "scene_test.npz")
+    U.save_scene(path, views, mvs, 45, 0.6, 5.0)
+    scene = U.load_scene(path)
+    assert len(scene) == 2 and scene[0]["color"].shape == (S, S, 3) and scene[0]["depth"].dtype == np.float32
+    rr = WarpRenderer(1, S, 5, 4, near=0.1, far=200.0)
+    colors, depths = R.render_scene(rr, scene[:1], [mvs[0], WC.orbit(0.1, 0.0)], ssaa=5)
+    assert colors.shape == (2, S, S, 3) and depths.shape == (2, S, S, 3) and colors.dtype == np.uint8
+    src = (scene[0]["color"] * 255).astype(np.float64)
+    err = np.abs(colors[0].astype(np.float64) - src)
+    G.report("warp/free_view_identity", mean_abs_8bit=err.mean(), q95=np.quantile(err, 0.95))
+    assert err.mean() < 3.0 and np.quantile(err, 0.95) < 12.0
+    tr = R.trajectory("swing", 60, 1)
+    assert len(tr) == 60 and np.allclose(tr[0], WC.orbit(0.6, 0.0), atol=1e-6)
+
+
 def test_mesh_build_full_size_batch_matches_oracle():
     S, B = 128, 3
     rgbd = np.concatenate([WC.synthetic_rgbd(S, s) for s in range(B)])
