@@ -187,11 +187,14 @@ int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview,
  *   R       : render size (S * ssaa);  rnear/rfar: the renderer's own planes (0.01 / 200, :161)
  *   zbuf    : scratch u64 [NV][B][R*R]
  *   outputs : color8 u8 [B][R][R][3] (to8b of the resolved colour), depth_lin fp32 [B][R][R] (metric depth),
- *             mask_color / mask_depth u8 [B][R][R] */
+ *             mask_color / mask_depth u8 [B][R][R]
+ *   work / work_cap   : caller-owned queue of the LARGE triangles (skirt / discontinuity sheets seen from another
+ *                       camera): int32 [2 + 2*work_cap]; they are rasterised by one workgroup each in a second pass
+ *                       instead of by their own thread.  work_cap = 0 disables the second pass (slow, same result). */
 int ivid_warp_render(const float* verts, const unsigned char* diag, const float* colors, const float* campos, int NV,
                      int B, int S, const float* mvp, int R, float rnear, float rfar, unsigned long long* zbuf,
                      unsigned char* color8, float* depth_lin, unsigned char* mask_color, unsigned char* mask_depth,
-                     void* stream);
+                     int* work, int work_cap, void* stream);
 /* Step 3: aggregate_conditions' SSAA resolve (rgbd_3d/utils.py:450-467): Pillow-exact 8-bit LANCZOS R->S
  * (two integer passes; bounds int32 [S][2], coeffs int32 [S][ksize] with 22 fractional bits computed by the host),
  * centre-sample depth + project_depth (:61-67), masks > 75 % of the ssaa^2 sub-pixels, depth_edge (:311-332),

@@ -57,7 +57,8 @@ SIGNATURES = {
     "ivid_inpaint_cond": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ivid_mesh_build": (i32, [vp, i32, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float,
                               i32, vp, vp, vp, vp, vp, vp]),
-    "ivid_warp_render": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]),
+    "ivid_warp_render": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32,
+                               vp]),
     "ivid_warp_resolve": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, C.c_float, C.c_float, C.c_float,
                                 C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
 }

@@ -241,9 +241,47 @@ __device__ __forceinline__ Frag eval_frag(const TriSetup& s, double X, double Y)
 
 constexpr unsigned long long ZEMPTY = ~0ull;
 
+// Screen bounding box of a triangle; triangles with a vertex at / behind the eye plane get the whole target (the 2-D
+// homogeneous edge functions need no clipping).  Returns false when it lies outside the target.
+__device__ __forceinline__ bool tri_bbox(const TriSetup& s, int R, int& x0, int& x1, int& r0, int& r1) {
+  x0 = 0; x1 = R - 1; r0 = 0; r1 = R - 1;
+  if (s.all_front_w) {
+    const float xmin = fminf(s.xn[0], fminf(s.xn[1], s.xn[2])), xmax = fmaxf(s.xn[0], fmaxf(s.xn[1], s.xn[2]));
+    const float ymin = fminf(s.yn[0], fminf(s.yn[1], s.yn[2])), ymax = fmaxf(s.yn[0], fmaxf(s.yn[1], s.yn[2]));
+    if (xmax < -1.f || xmin > 1.f || ymax < -1.f || ymin > 1.f) return false;
+    const float h = 0.5f * R;
+    x0 = max(0, (int)floorf((xmin + 1.f) * h - 0.5f) - 0);
+    x1 = min(R - 1, (int)ceilf((xmax + 1.f) * h - 0.5f));
+    r0 = max(0, (int)floorf((1.f - ymax) * h - 0.5f));
+    r1 = min(R - 1, (int)ceilf((1.f - ymin) * h - 0.5f));
+  }
+  return x0 <= x1 && r0 <= r1;
+}
+
+// depth test '<' + in-order draw of one fragment: packed 64-bit atomicMin (24-bit window depth << 32 | triangle id)
+__device__ __forceinline__ void raster_pixel(const TriSetup& s, const float* pad, int t, int r, int x, int R, double step,
+                                             unsigned long long* zb) {
+  const double Y = 1.0 - (r + 0.5) * step, X = (x + 0.5) * step - 1.0;
+  const Frag f = eval_frag(s, X, Y);
+  if (!f.inside) return;
+  if (!s.front) {  // aggregation.fsh:22-23: back-facing skirt fragments are discarded (no depth write)
+    const double isum = 1.0 / f.sum;
+    const double pv = (f.l[0] * pad[0] + f.l[1] * pad[1] + f.l[2] * pad[2]) * isum;
+    if (pv > 0.001) return;
+  }
+  const unsigned d24 = (unsigned)(fminf(fmaxf(f.depth, 0.f), 1.f) * 16777215.0f + 0.5f);
+  atomicMin(&zb[(size_t)r * R + x], ((unsigned long long)d24 << 32) | (unsigned)t);
+}
+
+constexpr int RASTER_SMALL = 256;  // bounding boxes up to this many pixels are walked by the triangle's own thread
+
+// Pass 1: one thread per triangle.  Small triangles (the height field proper: a few pixels each) are rasterised in
+// place; large ones -- skirt and discontinuity sheets seen from another camera, up to the whole target when a vertex is
+// behind the eye -- are queued for pass 2 so that no thread walks a big box alone.  work[0] = counter, entries (mb, t).
 __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ verts, const unsigned char* __restrict__ diag,
                                                      int B, int P, const float* __restrict__ mvp, int R,
-                                                     unsigned long long* __restrict__ zbuf) {
+                                                     unsigned long long* __restrict__ zbuf, int* __restrict__ work,
+                                                     int work_cap) {
   const int Q = P - 1, ntri = 2 * Q * Q;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int view = blockIdx.y, b = blockIdx.z;
@@ -252,35 +290,66 @@ __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ v
   const float* V = verts + mb * P * P * 9;
   const TriSetup s = tri_setup(V, diag + mb * Q * Q, t, P, mvp + b * 16);
   if (!s.valid) return;
-  int x0 = 0, x1 = R - 1, r0 = 0, r1 = R - 1;
-  if (s.all_front_w) {
-    const float xmin = fminf(s.xn[0], fminf(s.xn[1], s.xn[2])), xmax = fmaxf(s.xn[0], fmaxf(s.xn[1], s.xn[2]));
-    const float ymin = fminf(s.yn[0], fminf(s.yn[1], s.yn[2])), ymax = fmaxf(s.yn[0], fmaxf(s.yn[1], s.yn[2]));
-    if (xmax < -1.f || xmin > 1.f || ymax < -1.f || ymin > 1.f) return;
-    const float h = 0.5f * R;
-    x0 = max(0, (int)floorf((xmin + 1.f) * h - 0.5f) - 0);
-    x1 = min(R - 1, (int)ceilf((xmax + 1.f) * h - 0.5f));
-    r0 = max(0, (int)floorf((1.f - ymax) * h - 0.5f));
-    r1 = min(R - 1, (int)ceilf((1.f - ymin) * h - 0.5f));
+  int x0, x1, r0, r1;
+  if (!tri_bbox(s, R, x0, x1, r0, r1)) return;
+  if ((x1 - x0 + 1) * (r1 - r0 + 1) > RASTER_SMALL && work_cap > 0) {
+    const int slot = atomicAdd(&work[0], 1);
+    if (slot < work_cap) {
+      work[2 + 2 * slot] = (int)mb;
+      work[3 + 2 * slot] = t;
+      return;
+    }  // queue full: fall through and walk it here (correct, only slower)
   }
   float pad[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) pad[k] = (((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1;
   unsigned long long* zb = zbuf + mb * R * R;
   const double step = 2.0 / R;
-  for (int r = r0; r <= r1; ++r) {
-    const double Y = 1.0 - (r + 0.5) * step;
-    for (int x = x0; x <= x1; ++x) {
-      const double X = (x + 0.5) * step - 1.0;
-      const Frag f = eval_frag(s, X, Y);
-      if (!f.inside) continue;
-      if (!s.front) {  // aggregation.fsh:22-23: back-facing skirt fragments are discarded (no depth write)
-        const double isum = 1.0 / f.sum;
-        const double pv = (f.l[0] * pad[0] + f.l[1] * pad[1] + f.l[2] * pad[2]) * isum;
-        if (pv > 0.001) continue;
+  for (int r = r0; r <= r1; ++r)
+    for (int x = x0; x <= x1; ++x) raster_pixel(s, pad, t, r, x, R, step, zb);
+}
+
+// Pass 2: one workgroup per queued triangle (grid-stride over the queue).  The box is cut into 16x16-pixel tiles; a wave
+// takes a tile, rejects it when one of the three (affine) edge functions is negative on all of it, else its 64 lanes
+// evaluate the 256 pixels.  Results are order-independent (atomicMin on (depth, id)).
+__global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict__ verts,
+                                                         const unsigned char* __restrict__ diag, int B, int P,
+                                                         const float* __restrict__ mvp, int R,
+                                                         unsigned long long* __restrict__ zbuf,
+                                                         const int* __restrict__ work, int work_cap) {
+  const int Q = P - 1;
+  const int count = min(work[0], work_cap);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double step = 2.0 / R;
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const size_t mb = (size_t)work[2 + 2 * i];
+    const int t = work[3 + 2 * i];
+    const int b = (int)(mb % B);
+    const float* V = verts + mb * P * P * 9;
+    const TriSetup s = tri_setup(V, diag + mb * Q * Q, t, P, mvp + b * 16);
+    int x0, x1, r0, r1;
+    tri_bbox(s, R, x0, x1, r0, r1);
+    float pad[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pad[k] = (((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1;
+    unsigned long long* zb = zbuf + mb * R * R;
+    const int tx0 = x0 >> 4, ty0 = r0 >> 4;
+    const int ntx = (x1 >> 4) - tx0 + 1, nty = (r1 >> 4) - ty0 + 1;
+    for (int ti = wave; ti < ntx * nty; ti += 4) {
+      const int ty = ty0 + ti / ntx, tx = tx0 + ti % ntx;
+      const int px0 = max(x0, tx << 4), px1 = min(x1, (tx << 4) + 15), pr0 = max(r0, ty << 4), pr1 = min(r1, (ty << 4) + 15);
+      // pixel-centre extent of the tile in NDC
+      const double X0 = (px0 + 0.5) * step - 1.0, X1 = (px1 + 0.5) * step - 1.0;
+      const double Y0 = 1.0 - (pr1 + 0.5) * step, Y1 = 1.0 - (pr0 + 0.5) * step;
+      bool out = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // max of the affine edge function over the tile
+        const double m = s.a[k] * (s.a[k] >= 0.0 ? X1 : X0) + s.b[k] * (s.b[k] >= 0.0 ? Y1 : Y0) + s.c[k];
+        out = out || m < 0.0;
       }
-      const unsigned d24 = (unsigned)(fminf(fmaxf(f.depth, 0.f), 1.f) * 16777215.0f + 0.5f);
-      atomicMin(&zb[(size_t)r * R + x], ((unsigned long long)d24 << 32) | (unsigned)t);
+      if (out) continue;
+      const int w = px1 - px0 + 1, n = w * (pr1 - pr0 + 1);
+      for (int p = lane; p < n; p += 64) raster_pixel(s, pad, t, pr0 + p / w, px0 + p % w, R, step, zb);
     }
   }
 }
@@ -515,13 +584,23 @@ extern "C" int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv
 extern "C" int ivid_warp_render(const float* verts, const unsigned char* diag, const float* colors, const float* campos,
                                 int NV, int B, int S, const float* mvp, int R, float rnear, float rfar,
                                 unsigned long long* zbuf, unsigned char* color8, float* depth_lin,
-                                unsigned char* mask_color, unsigned char* mask_depth, void* stream) {
+                                unsigned char* mask_color, unsigned char* mask_depth, int* work, int work_cap,
+                                void* stream) {
   if (NV <= 0 || B <= 0 || R <= 0) return ivid_set_error("warp_render: bad size", hipSuccess);
+  if (work_cap < 0 || (work_cap > 0 && !work)) return ivid_set_error("warp_render: bad work queue", hipSuccess);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)NV * B * R * R * sizeof(unsigned long long), s);
   if (e != hipSuccess) return ivid_set_error("warp_render: memset", e);
+  if (work_cap > 0) {
+    e = hipMemsetAsync(work, 0, 2 * sizeof(int), s);
+    if (e != hipSuccess) return ivid_set_error("warp_render: memset", e);
+  }
   const int P = S + 2, ntri = 2 * (P - 1) * (P - 1);
-  hipLaunchKernelGGL(raster_kernel, dim3((ntri + 255) / 256, NV, B), dim3(256), 0, s, verts, diag, B, P, mvp, R, zbuf);
+  hipLaunchKernelGGL(raster_kernel, dim3((ntri + 255) / 256, NV, B), dim3(256), 0, s, verts, diag, B, P, mvp, R, zbuf,
+                     work, work_cap);
+  if (work_cap > 0)
+    hipLaunchKernelGGL(raster_big_kernel, dim3(work_cap < 8192 ? work_cap : 8192), dim3(256), 0, s, verts, diag, B, P, mvp, R,
+                       zbuf, work, work_cap);
   hipLaunchKernelGGL(aggregate_kernel, dim3((R * R + 255) / 256, B), dim3(256), 0, s, verts, diag, colors, campos, NV, B,
                      S, mvp, R, zbuf, rnear, rfar, color8, depth_lin, mask_color, mask_depth);
   return ivid_check_launch("warp_render");

@@ -9,6 +9,8 @@ Here the whole view loop stays on the GPU: `add_view` turns the B freshly sample
 with one call, `conditions` rasterises all source views of all samples and resolves the conditioning tensors
 the conditional sampler needs, all as a handful of launches on the current stream.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -36,6 +38,11 @@ class WarpRenderer:
         self.scratch_depth = torch.empty(B, P * P, dtype=f32, device=dev)
         self.scratch_flags = torch.empty(B, P * P, dtype=torch.int32, device=dev)
         self.zbuf = torch.empty(NV, B, R * R, dtype=torch.int64, device=dev)
+        # queue of the large triangles (second rasterisation pass): counter + (mesh, triangle) pairs
+        # (skirt: 8 (S+1) triangles per mesh, + discontinuity sheets; 4096 per mesh leaves a 3x margin at S = 128 --
+        #  an overflowing queue only costs speed, the kernel then walks the triangle in its own thread)
+        self.work_cap = int(os.environ.get("IVID_WARP_QUEUE", str(NV * B * max(4096, 32 * (S + 1)))))
+        self.work = torch.zeros(2 + 2 * max(self.work_cap, 1), dtype=torch.int32, device=dev)
         self.color8 = torch.empty(B, R, R, 3, dtype=u8, device=dev)
         self.depth_lin = torch.empty(B, R, R, dtype=f32, device=dev)
         self.mask_c = torch.empty(B, R, R, dtype=u8, device=dev)
@@ -101,7 +108,7 @@ class WarpRenderer:
         _lib.call("ivid_warp_render", _lib.ptr(self.verts), _lib.ptr(self.diag), _lib.ptr(self.colors),
                   _lib.ptr(self.campos), self.num_views, self.B, self.S, _lib.ptr(mvp_d), self.R, self.near, self.far,
                   _lib.ptr(self.zbuf), _lib.ptr(self.color8), _lib.ptr(self.depth_lin), _lib.ptr(self.mask_c),
-                  _lib.ptr(self.mask_d), self._stream())
+                  _lib.ptr(self.mask_d), _lib.ptr(self.work), self.work_cap, self._stream())
         return AttrDict(color8=self.color8, depth=self.depth_lin, mask_color=self.mask_c, mask_depth=self.mask_d)
 
     @torch.no_grad()
