@@ -224,7 +224,7 @@ def main():
                 json.dump(rows, f, indent=0)
         result["forward_ms_eager_events"] = round(total_ms, 3)
 
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N = 1 only (a host-side figure)
         # the oracle (a CPU restatement of the reference forward, pinned to it bit-for-bit by tests/golden) on the
         # host cores: 1 warm-up + 2 timed forwards at bs 2, fp32
         from oracle import adm_oracle
