@@ -18,6 +18,7 @@ import torch
 from .. import parallel, rgbd_3d
 from ..diffusion import backbones, frameworks, samplers
 from ..utils import AttrDict
+from .superres import super_resolve
 from .utils import colorize_depth, parse_int_list, reorder, save_grid, save_png, save_scene
 
 
@@ -162,6 +163,13 @@ def main(argv=None):
     p.add_argument("--rtol", type=float, default=0.03)
     p.add_argument("--erode_rgb", type=int, default=3)
     p.add_argument("--precision", type=str, default=None, help="fp32 (parity) | bf16 (perf); default: from config use_fp16")
+    # 128 -> 256 super-resolution of every generated view (BASELINE config 5).  Not in the reference CLI: the reference ships
+    # the SR model and SuperResCFG but no inference driver for them (only SuperResTrainer.sample, trainers/superres.py:97-134)
+    p.add_argument("--config_sr", type=str, default=None, help="e.g. configs/rgbd_imagenet_adm_256_128_small_sr.json")
+    p.add_argument("--ckpt_sr", type=str, default=None)
+    p.add_argument("--steps_sr", type=int, default=50)
+    p.add_argument("--guidance_sr", type=float, default=3.0)
+    p.add_argument("--batchsize_sr", type=int, default=16)
     opt = p.parse_args(argv)
     cfg = AttrDict(vars(opt))
     with open(opt.config_uncond) as f:
@@ -196,6 +204,11 @@ def main(argv=None):
 
     fw_uncond = build_model(cfg_uncond, cfg.ckpt_uncond, device, cfg.precision)
     fw_cond = build_model(cfg_cond, cfg.ckpt_cond, device, cfg.precision) if cfg.viewset != "uncond" else None
+    fw_sr = None
+    if cfg.config_sr is not None:
+        with open(cfg.config_sr) as f:
+            fw_sr = build_model(json.load(f), cfg.ckpt_sr, device, cfg.precision)
+        os.makedirs(os.path.join(cfg.output_dir, "results_sr"), exist_ok=True)
 
     # rank-strided partition, identical to sample.py:199-202
     seeds_r = parallel.shard(seeds, rank, world)
@@ -211,6 +224,13 @@ def main(argv=None):
         if classes_r is not None:
             parts.append(f"class{classes_r[i]:03d}")
         parts.append(f"seed{seeds_r[i]:05d}" if seeds_r is not None else f"{idx[i]:05d}")
+        if fw_sr is not None:   # the chain uncond -> warp/inpaint views -> SR stays on the GPU
+            hi = super_resolve(fw_sr, samples, classes=classes_r[i] if classes_r is not None else None, steps=cfg.steps_sr,
+                               strength=cfg.guidance_sr, batchsize=cfg.batchsize_sr)
+            torch.cuda.synchronize(device)
+            hi = hi.cpu()
+            for v in range(hi.shape[0]):
+                save_png(os.path.join(cfg.output_dir, "results_sr", f"rgb_{'_'.join(parts)}_view{v:02d}.png"), hi[v, :3])
         torch.cuda.synchronize(device)
         mv_i = views_r[i] if isinstance(views_r[0], list) else views_r
         threads.append(async_save(samples, conds, "_".join(parts), cfg, mv_i))
