@@ -124,6 +124,12 @@ int ivid_silu_f32(const float* x, float* y, long long n, void* stream);
  * fp32 NCHW [Bsrc,Cin,H,W] -> NHWC dtype [N,H,W,Cpad] (zero padded channels, batch replicated n % Bsrc). */
 int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Cpad, void* out,
                       void* stream);
+/* Stem convolution input (adm.py:369 `input_blocks[0]`, a 3x3 conv on the 4..10 model input channels): instead of a
+ * channel-padded NHWC copy, lay out every pixel's 3x3 patch as one K row  k = tap*Cin + c  (zero-padded taps, zeros for
+ * k >= 9*Cin), so the stem runs as ivid_conv2d(taps = 1, C0 = Kpad) with weights [Cout][Kpad] in the same k order.
+ *   x fp32 NCHW [Bsrc,Cin,H,W]; row n reads source n % Bsrc (the stacked CFG batch);  out [N,H,W,Kpad] in `dtype`. */
+int ivid_stem_im2col(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
+                     void* stream);
 
 /* ---- samplers (fp32 NCHW [B,4,H,W]) ----
  * eps = (1+s)*eps_c - s*eps_u (classifier_free_guidance.py:39-42); eps_u may be NULL (s ignored). */

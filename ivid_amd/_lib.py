@@ -52,6 +52,7 @@ SIGNATURES = {
     "ivid_embed_inputs": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "ivid_silu_f32": (i32, [vp, vp, i64, vp]),
     "ivid_nchw_to_nhwc": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_stem_im2col": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ivid_ddpm_step": (i32, [vp, vp, vp, C.POINTER(DdpmCoef), vp, vp, vp, i32, i32, vp]),
     "ivid_inpaint_cond": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

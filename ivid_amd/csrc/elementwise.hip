@@ -56,6 +56,38 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// Stem im2col: the model input has only 4..10 channels, so a 3x3 implicit GEMM over a channel-padded NHWC copy spends 9
+// K-steps on 94 % zeros.  Instead the 3x3 patch of every pixel is laid out as ONE K row  k = tap*Cin + c  (zero for padded
+// taps and for k >= 9 Cin), and the stem becomes a 1x1 GEMM with K = Kpad (one K-step for Cin <= 7).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, int Bsrc, int Cin, int H, int W,
+                                                          int Kpad, char* __restrict__ out) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  const int HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (p >= HW) return;
+  const int y = p / W, xx = p - y * W;
+  const float* xs = x + (size_t)(n % Bsrc) * Cin * HW;
+  char* o = out + ((size_t)n * HW + p) * Kpad * sizeof(T);
+  const int K = 9 * Cin;
+  for (int k0 = 0; k0 < Kpad; k0 += VE) {
+    float f[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int k = k0 + e;
+      float v = 0.f;
+      if (k < K) {
+        const int tap = k / Cin, c = k - tap * Cin;
+        const int yy = y + tap / 3 - 1, xc = xx + tap % 3 - 1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xc < (unsigned)W) v = xs[(size_t)c * HW + yy * W + xc];
+      }
+      f[e] = v;
+    }
+    *(vec_t*)(o + k0 * sizeof(T)) = f32_to_vec<T>(f);
+  }
+}
+
 struct StepPtrs {
   const float *x_t, *eps_c, *eps_u, *rgb, *rgb_mask, *depth, *depth_mask, *convex, *noise;
   float *x_prev, *x0;
@@ -170,6 +202,22 @@ extern "C" int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int
   else
     return ivid_set_error("nchw_to_nhwc: bad dtype", hipSuccess);
   return ivid_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int ivid_stem_im2col(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
+                                void* stream) {
+  const int ve = dtype == IVID_F32 ? 4 : 8;
+  if (Kpad % ve || Kpad < 9 * Cin || Cin <= 0) return ivid_set_error("stem_im2col: bad Kpad", hipSuccess);
+  dim3 grid((H * W + 255) / 256, N);
+  if (dtype == IVID_F32)
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
+                       (char*)out);
+  else if (dtype == IVID_BF16)
+    hipLaunchKernelGGL(stem_im2col_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
+                       (char*)out);
+  else
+    return ivid_set_error("stem_im2col: bad dtype", hipSuccess);
+  return ivid_check_launch("stem_im2col");
 }
 
 extern "C" int ivid_ddim_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddim_coef* host_coef,

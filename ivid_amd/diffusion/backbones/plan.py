@@ -53,8 +53,11 @@ class PackedWeights:
             t[name + ".weight"] = g(name + ".weight").contiguous()
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
-        self.cin_pad = _pad_to(spec.in_channels, self.kstep)
-        conv3("input_blocks.0.0", self.cin_pad)
+        # stem: the 3x3 patch of the few input channels is ONE K row (k = tap*Cin + c, ivid_stem_im2col), padded to a K-step
+        self.stem_k = _pad_to(9 * spec.in_channels, self.kstep)
+        ws = g("input_blocks.0.0.weight").permute(0, 2, 3, 1).reshape(spec.stem_out, -1)   # [Cout, 9*Cin]
+        t["input_blocks.0.0.weight"] = torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])).to(tdt).contiguous()
+        t["input_blocks.0.0.bias"] = g("input_blocks.0.0.bias").contiguous()
         emb_w, emb_b = [], []
         for op in [o for st in spec.stages for o in st.ops]:
             p = op.prefix
@@ -343,11 +346,10 @@ class UNetPlan:
         self._linear(semb, ed, "emb_all", self.embproj, sp.emb_total)
         # ---- stem ----
         S = sp.image_size
-        xin = self._new(n, S, w.cin_pad)
-        self._rec("ivid_nchw_to_nhwc", self.dtype, self.x_in.data_ptr(), self.bsrc, n, sp.in_channels, S, S, w.cin_pad,
-                  xin.ptr)
+        xin = self._new(n, S, w.stem_k)
+        self._rec("ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n, sp.in_channels, S, S, w.stem_k, xin.ptr)
         h = self._new(n, S, sp.stem_out, stats=True)
-        self._conv(self.dtype, xin.ptr, w.cin_pad, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 9,
+        self._conv(self.dtype, xin.ptr, w.stem_k, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 1,
                    out_act=h)
         self._free(xin)
         self._tap("stem", h)

@@ -220,6 +220,42 @@ def test_conv3x3_gn_fused_with_skip_conv(case, dtype):
     assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin", [4, 8, 10])
+def test_stem_im2col_then_1x1_equals_the_3x3_stem_conv(cin, dtype):
+    """input_blocks[0] (adm.py:369): ivid_stem_im2col + ivid_conv2d(taps=1) vs F.conv2d(x, w, b, padding=1), including the
+    stacked-CFG batch rule (row n reads source n % Bsrc) and non-square H != W."""
+    L = G.lib()
+    Bsrc, N, H, W, Cout = 2, 4, 16, 32, 64
+    x = common.seeded_randn(10 + cin, Bsrc, cin, H, W)
+    w = common.seeded_randn(20 + cin, Cout, cin, 3, 3) / np.sqrt(9 * cin)
+    b = common.seeded_randn(30 + cin, Cout) * 0.1
+    kstep = 32 if dtype == 0 else 64
+    kpad = (9 * cin + kstep - 1) // kstep * kstep
+    cols = torch.full((N, H, W, kpad), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    xd = x.cuda()
+    L.call("ivid_stem_im2col", dtype, L.ptr(xd), Bsrc, N, cin, H, W, kpad, L.ptr(cols), G.stream())
+    torch.cuda.synchronize()
+    # the columns themselves: exact (a copy, rounded to the compute dtype)
+    xp = F.pad(G.rounded(x, dtype), (1, 1, 1, 1))
+    ref_cols = torch.zeros(Bsrc, H, W, kpad)
+    for tap in range(9):
+        dy, dx = tap // 3, tap % 3
+        ref_cols[..., tap * cin:(tap + 1) * cin] = xp[:, :, dy:dy + H, dx:dx + W].permute(0, 2, 3, 1)
+    assert torch.equal(cols.float().cpu(), ref_cols.repeat(2, 1, 1, 1))
+    wp = torch.zeros(Cout, kpad)
+    wp[:, :9 * cin] = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    wd, bd = wp.to("cuda", G.tdt(dtype)), b.cuda()
+    L.call("ivid_conv2d", dtype, L.ptr(cols), kpad, None, 0, L.ptr(wd), L.ptr(bd), L.ptr(out), None, 0,
+           0, N, H, W, Cout, 1, 0, None, G.stream())
+    torch.cuda.synchronize()
+    ref = F.conv2d(G.rounded(x, dtype).double(), G.rounded(w, dtype).double(), b.double(), padding=1).float().repeat(2, 1, 1, 1)
+    e = common.rel_l2(G.from_nhwc(out), ref)
+    G.report(f"stem_im2col/cin{cin}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e)
+    assert e < G.tol(dtype, 2e-6, 4e-3), e
+
+
 def test_conv2d_is_transpose_detecting_identity_weights():
     # A = asymmetric ramp, W = identity 1x1: out must equal in exactly (catches swapped C/D row/col maps)
     N, H, W, Cc = 1, 16, 16, 128
