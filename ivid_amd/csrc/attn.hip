@@ -13,6 +13,7 @@
 //          applied to the V^T fragment, so no cross-lane movement of P is needed.)
 // bf16 mode: v_mfma_f32_32x32x16_bf16; V is transposed into LDS as Vt[d][kv] while staging.
 // fp32 mode: v_mfma_f32_32x32x2_f32 (exact); V stays [kv][d] (one float per lane per MFMA).
+#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 
@@ -31,8 +32,8 @@ template <> struct AttnCfg<float> {
   static __device__ __forceinline__ int swz(int row) { return row & 15; }
 };
 
-template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const char* __restrict__ qkv, char* __restrict__ out, int T_,
+template <typename T, int NW, int WPE = 2>
+__global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restrict__ qkv, char* __restrict__ out, int T_,
                                                        int heads) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -127,11 +128,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const char* __restrict__ 
 #pragma unroll
     for (int kvh = 0; kvh < 2; ++kvh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[kvh][r] *= sc;
-        mt = fmaxf(mt, s[kvh][r]);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kvh][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32)) * sc;  // sc > 0: the max of the scaled scores (log2 domain)
     const float m_new = fmaxf(m_run, mt);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
@@ -139,16 +137,18 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const char* __restrict__ 
     for (int kvh = 0; kvh < 2; ++kvh)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[kvh][r] = __builtin_amdgcn_exp2f(s[kvh][r] - m_new);
+        s[kvh][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvh][r], sc, -m_new));  // scale folded into the exponent
         ps += s[kvh][r];
       }
     ps += __shfl_xor(ps, 32);
     l_run = l_run * alpha + ps;
     m_run = m_new;
+    if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running maxima rarely move
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T ----
     if constexpr (IS_BF16) {
@@ -224,6 +224,17 @@ extern "C" int ivid_attention(int dtype, const void* qkv, void* out, int N, int 
 #define LAUNCH(TT, NW) \
   hipLaunchKernelGGL((attn_kernel<TT, NW>), grid, dim3(NW * 64), 0, s, (const char*)qkv, (char*)out, T, heads)
   if (dtype == IVID_BF16) {
+#ifdef IVID_DEV_ABLATE
+    static const int wpe = getenv("IVID_ATTN_WPE") ? atoi(getenv("IVID_ATTN_WPE")) : 2;
+    if (four && wpe == 4) {
+      hipLaunchKernelGGL((attn_kernel<__bf16, 4, 4>), grid, dim3(256), 0, s, (const char*)qkv, (char*)out, T, heads);
+      return ivid_check_launch("attention");
+    }
+    if (four && wpe == 3) {
+      hipLaunchKernelGGL((attn_kernel<__bf16, 4, 3>), grid, dim3(256), 0, s, (const char*)qkv, (char*)out, T, heads);
+      return ivid_check_launch("attention");
+    }
+#endif
     if (four) LAUNCH(__bf16, 4); else LAUNCH(__bf16, 2);
   } else {
     if (four) LAUNCH(float, 4); else LAUNCH(float, 2);
