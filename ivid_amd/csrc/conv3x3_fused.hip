@@ -417,6 +417,19 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's 128 pixels (fused gn_partial)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    const int y = y0 + wm * 4 + mi;                        // this fragment = image row y, pixels x0 .. x0+31
+    const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;
+    const int nbase = n0 + wn * WTN;
+    constexpr int LPR = WTN / VE, RPP = 64 / LPR;
+    const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+    // same-size residual: all of the fragment's loads are issued BEFORE the transpose, so their latency hides behind
+    // the slab traffic instead of sitting in front of every store
+    vec_t rres[32 / RPP];
+    if (p.res_mode == 1 && nbase + lc < Cout) {
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps)
+        rres[ps] = *(const vec_t*)(p.res + ((mbase + ps * RPP + lr) * Cout + nbase + lc) * sizeof(T));
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -425,11 +438,6 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
       }
     wave_lds_sync();  // the slab is private to this wave
-    const int y = y0 + wm * 4 + mi;                        // this fragment = image row y, pixels x0 .. x0+31
-    const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;
-    const int nbase = n0 + wn * WTN;
-    constexpr int LPR = WTN / VE, RPP = 64 / LPR;
-    const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
     if (mi == 0) {
 #pragma unroll
       for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
         if (p.res_mode == 1) {
           float rv[VE];
-          vec_to_f32<T>(*(const vec_t*)(p.res + (m * Cout + n) * sizeof(T)), rv);
+          vec_to_f32<T>(rres[ps], rv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += rv[e];
         } else if (p.res_mode == 2) {

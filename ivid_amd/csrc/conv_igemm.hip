@@ -260,6 +260,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's WTM pixels (fused gn_partial)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    const int mbase = m0 + wm * WTM + mi * 32;
+    const int nbase = n0 + wn * WTN;
+    constexpr int LPR = WTN / VE;   // lanes per slab row
+    constexpr int RPP = 64 / LPR;   // rows per pass
+    const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+    // same-size residual: all of the fragment's loads are issued BEFORE the transpose, so their latency hides behind
+    // the slab traffic instead of sitting in front of every store
+    vec_t rres[32 / RPP];
+    if (p.out_mode == 0 && p.res_mode == 1) {
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int m = mbase + ps * RPP + lr, n = nbase + lc;
+        if (m < p.M && n < Cout) rres[ps] = *(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T));
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -268,12 +283,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
       }
     wave_lds_sync();  // the slab is private to this wave
-    const int mbase = m0 + wm * WTM + mi * 32;
-    const int nbase = n0 + wn * WTN;
     if (p.out_mode == 0) {
-      constexpr int LPR = WTN / VE;   // lanes per slab row
-      constexpr int RPP = 64 / LPR;   // rows per pass
-      const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
       // statistics blocks are ALWAYS 64 consecutive pixels (32 for the narrow tile), whatever tile the launch uses:
       // the fp32 summation order is then independent of the batch-size-dependent tile choice, so a sample's result
       // is bit-identical in any batch (in bf16 mode a 1e-7 change of a GroupNorm coefficient decorrelates rounding
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
           if (p.res_mode == 1) {
             float rv[VE];
-            vec_to_f32<T>(*(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T)), rv);
+            vec_to_f32<T>(rres[ps], rv);
 #pragma unroll
             for (int e = 0; e < VE; ++e) v[e] += rv[e];
           } else if (p.res_mode != 0) {

@@ -39,6 +39,8 @@ def main():
             w.zero_()
         b = torch.randn(cout, device="cuda")
         out = torch.empty(n, h, h, cout, device="cuda", dtype=tdt)
+        res = torch.randn(n, h, h, cout, device="cuda").to(tdt) if os.environ.get("RES") == "1" else None   # same-size residual
+        rp, rm = (res.data_ptr(), 1) if res is not None else (None, 0)
         flop = 2.0 * n * h * h * cout * taps * cin
         ab = torch.rand(n, cin, 2, device="cuda") + 0.5
         for cfg in cfgs:
@@ -48,9 +50,9 @@ def main():
             def launch():
                 if cfg == -1:   # the fused GN-apply + SiLU + conv3x3 kernel
                     _lib.check(lib.ivid_conv3x3_gn(dtype, x.data_ptr(), cin, None, 0, ab.data_ptr(), 0, w.data_ptr(), b.data_ptr(),
-                                                   out.data_ptr(), None, 0, n, h, h, cout, None, sp), "conv3x3_gn")
+                                                   out.data_ptr(), rp, rm, n, h, h, cout, None, sp), "conv3x3_gn")
                 else:
-                    _lib.check(lib.ivid_conv2d(dtype, x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None, 0, 0,
+                    _lib.check(lib.ivid_conv2d(dtype, x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), rp, rm, 0,
                                                n, h, h, cout, taps, cfg, None, sp), "conv")
             launch()
             torch.cuda.synchronize()
