@@ -258,6 +258,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   float* slab = (float*)smem + wave * (32 * LDC);
   const int Cout = p.Cout;
   float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's WTM pixels (fused gn_partial)
+  float bv[VE];              // this lane's bias values (NHWC path): the same 16-byte channel piece in every pass
+  {
+    const int nb = n0 + wn * WTN + (lane % (WTN / VE)) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) bv[e] = (p.bias && nb < Cout) ? p.bias[nb + e] : 0.f;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int mbase = m0 + wm * WTM + mi * 32;
@@ -304,10 +310,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
             const f32x4 t = *(const f32x4*)(slab + row * LDC + lc + e);
             v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
           }
-          if (p.bias) {
 #pragma unroll
-            for (int e = 0; e < VE; ++e) v[e] += p.bias[n + e];
-          }
+          for (int e = 0; e < VE; ++e) v[e] += bv[e];
           if (p.res_mode == 1) {
             float rv[VE];
             vec_to_f32<T>(rres[ps], rv);
