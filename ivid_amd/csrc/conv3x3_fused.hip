@@ -197,6 +197,21 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16_s(wk, b_voff[i], sB + (i * NT + wave * 64) * 16);
   };
+  // The same slab staged by the LAGGING wave group alone (256 threads x 8 pieces, rows 32 apart): in the ping-pong loop
+  // all weight DMA is issued from that group's phase 1, so the leading group's MFMA phase holds nothing but MFMAs and
+  // fragment reads (measured: its issue window cost ~600 of 1800 cycles there).
+  const int g1_row = (tid & 255) >> 3;
+  const unsigned g1_swz = ((tid & 7) ^ ((g1_row >> 1) & 7)) << 4;
+  const int krow_bytes = (int)(Ktot * sizeof(T));   // < 2^24 (checked on the host)
+  auto issue_b_g1 = [&](int stage, int ch, int tap) {
+    char* sB = sB0 + stage * B_BYTES;
+    const char* wk = p.w + ((size_t)tap * Ctot + (size_t)ch * BKE) * sizeof(T);  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(n0 + g1_row + 32 * i, p.Cout - 1);
+      glds16_s(wk, __umul24(row, krow_bytes) + g1_swz, sB + (i * 256 + (wave - 4) * 64) * 16);
+    }
+  };
 
   const int frow = lane & 31, fhalf = lane >> 5;
   // weight fragment (ni = 0, k-piece 0) inside a stage; fragment ni adds 32 rows = 4096 B (same swizzle), k-piece kk
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // two halves in OPPOSITE order: while one group transforms its halo piece (VALU + transcendental pipes) the other
   // owns the matrix pipe, then they swap; both meet at the next step's barrier.  Fragment registers rotate: a fragment
   // is re-requested for k-piece kk+1 right after its last MFMA of k-piece kk has been issued.
+  unsigned long long pc_other = 0, pc_mma = 0, pc_barx = 0, pc_bary = 0;   // development phase counters (AB & 256)
   auto chunk_body = [&](const int ch, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
@@ -255,9 +271,13 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         // Counted waits: the raw halo piece of the latest issue window (always the newest VMEM operation of a wave,
         // issued AFTER the weights) may stay in flight -- it is consumed three steps later; everything older has landed.
         const bool prev_loaded = !(AB & 2) && MORE && tap >= 1 && tap <= 6;
+        unsigned long long tq0 = 0;
+        if (AB & 256) tq0 = __builtin_readcyclecounter();
         if (prev_loaded) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else wait_vmcnt0();
         __syncthreads();  // barrier X
+        unsigned long long tq1 = 0;
+        if (AB & 256) { tq1 = __builtin_readcyclecounter(); pc_barx += tq1 - tq0; }
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
@@ -267,14 +287,14 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         asm volatile("" : "+v"(cur));  // pins the copy (and the compiler's vmcnt for it) here
         if (do_load && tap == 1) ab_store(abq, sAn);
         // issue window of the step: weights of the NEXT K-step, then one raw halo piece of the next chunk
-        auto issue_window = [&]() {
-          if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
-          if (do_load) {
-            if (tap == 0) abq = ab_load(ch + 1);
-            raw[t] = load_piece(3 * g + t, csn);
-          }
-        };
-        if (wm == 1) issue_window();  // the lagging group's window: global time = the leading group's MFMA phase
+        // issue window of the step (both groups in phase 1): the lagging group stages the whole weight slab of the NEXT
+        // K-step (global time = the leading group's MFMA phase: the stage it overwrites was read until the last barrier),
+        // then every wave requests one raw halo piece of the next chunk
+        if (wm == 1 && !(AB & 1) && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        if (do_load) {
+          if (tap == 0) abq = ab_load(ch + 1);
+          raw[t] = load_piece(3 * g + t, csn);
+        }
         // ---- fragments of k-piece 0 ----
         vec_t a[MI], b[NI];
 #pragma unroll
@@ -318,15 +338,19 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         };
         if (do_store) xform_store(3 * (g - 1) + t, cur, sAn);
         // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
+        unsigned long long tq2 = 0;
+        if (AB & 256) { tq2 = __builtin_readcyclecounter(); pc_other += tq2 - tq1; }
         if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else wait_vmcnt0();
         __syncthreads();  // barrier Y
-        if (wm == 0) issue_window();  // the leading group's window (the stage it overwrites was read until barrier Y)
+        unsigned long long tq3 = 0;
+        if (AB & 256) { tq3 = __builtin_readcyclecounter(); pc_bary += tq3 - tq2; }
         __builtin_amdgcn_sched_barrier(0);
         if (AB & 64) __builtin_amdgcn_s_setprio(1);
         mma_block();
         if (AB & 64) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (AB & 256) pc_mma += __builtin_readcyclecounter() - tq3;
       }
     }
   };
@@ -339,7 +363,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // group 0 reads it.  Halo image c+1 is written in phase 1 of taps 3..8 of chunk c and first read after two more
   // barriers; its previous content was last read three steps before the first write.
   wait_vmcnt0();
-  if (AB & 256) ts[1] = wall_clock64();
+  unsigned long long cyc1 = 0;
+  if (AB & 256) { ts[1] = wall_clock64(); cyc1 = __builtin_readcyclecounter(); }
   if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
@@ -406,7 +431,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       }
     }
   }
-  if (AB & 256) ts[2] = wall_clock64();
+  unsigned long long cyc2 = 0;
+  if (AB & 256) { ts[2] = wall_clock64(); cyc2 = __builtin_readcyclecounter(); }
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   wait_vmcnt0();
@@ -512,7 +538,11 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     if (tid == 0) {
       unsigned long long* o = (unsigned long long*)p.stats + (size_t)blockIdx.x * 5;
       o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3];
-      o[4] = __smid();
+      o[4] = cyc2 - cyc1;   // shader-clock cycles of the main loop (s_memtime): / (ts[2]-ts[1]) * 100 MHz = sustained clock
+    }
+    if (lane == 0 && (wave == 0 || wave == 4)) {   // phase cycle counters of one wave of each ping-pong group
+      unsigned long long* q = (unsigned long long*)p.stats + (size_t)p.ntiles_total * 5 + ((size_t)blockIdx.x * 2 + wm) * 4;
+      q[0] = pc_other; q[1] = pc_mma; q[2] = pc_barx; q[3] = pc_bary;
     }
   }
 }
@@ -551,7 +581,7 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
     return ivid_set_error("conv3x3_gn: skip source / weight missing", hipSuccess);
   {  // the kernel addresses one image / the weight matrix with 32-bit byte offsets from a 64-bit wave-uniform base
     const size_t hs = up ? H / 2 : H, ws = up ? W / 2 : W, cmax = C0 > C1 ? C0 : C1, smax = skipC0 > skipC1 ? skipC0 : skipC1;
-    if (hs * ws * cmax * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * (C0 + C1) * esz >= ((size_t)1 << 32) ||
+    if ((size_t)9 * (C0 + C1) * esz >= ((size_t)1 << 24) || hs * ws * cmax * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * (C0 + C1) * esz >= ((size_t)1 << 32) ||
         (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
