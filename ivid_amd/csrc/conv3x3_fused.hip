@@ -18,7 +18,7 @@
 //   B operand : the [256 cout x 128 B] weight slab of (chunk, tap) streams through a 2-stage LDS ring with
 //               global_load_lds, exactly as in conv_igemm.hip.
 //   schedule  : K-step = (chunk, tap); taps are unrolled, each tap issues the raw load of ONE halo piece of the NEXT
-//               chunk and, three taps later (right after the step's barrier, when everything in flight has landed),
+//               chunk and, two taps later (right after the step's barrier, when everything older in flight has landed),
 //               transforms + stores it: at most 3 pieces (12 VGPRs) are in flight and the VALU work is spread evenly.
 #include <cstdlib>
 #include <type_traits>
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 
   // ---------------- main loop ----------------
   // K-step = (chunk, tap), tap = 3g + t with (dy, dx) = (g-1, t-1); the 9 taps of a chunk are unrolled (straight-line
-  // code, static register indices).  Halo pipeline of the NEXT chunk: at tap 3g+t slot t of raw[] is consumed (piece
-  // 3(g-1)+t, issued three taps ago: transformed and stored) and refilled (piece 3g+t); its coefficients are fetched at
+  // code, static register indices).  Halo pipeline of the NEXT chunk: at tap k slot k&1 of raw[] is consumed (piece k-2,
+  // requested two taps ago: transformed and stored, taps 2..7) and refilled (piece k, taps 0..5); its coefficients are fetched at
   // tap 0 and parked in LDS at tap 1.  The two wave groups (wm = 0 / 1: waves w and w+4 share a SIMD) run the step's
   // two halves in OPPOSITE order: while one group transforms its halo piece (VALU + transcendental pipes) the other
   // owns the matrix pipe, then they swap; both meet at the next step's barrier.  Fragment registers rotate: a fragment
@@ -258,15 +258,15 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
     char* sAn = sA0 + ((ch + 1) & 1) * A_BYTES;
     const ChunkSrc csn = chunk_src(MORE ? ch + 1 : ch);
-    vec_t raw[3];
+    vec_t raw[2];
     f32x4 abq;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int tap = 3 * g + t;
-        const bool do_store = !(AB & 2) && MORE && g >= 1;
-        const bool do_load = !(AB & 2) && MORE && g <= 1;
+        const bool do_store = !(AB & 2) && MORE && tap >= 2 && tap <= 7;   // piece tap-2, requested two taps ago
+        const bool do_load = !(AB & 2) && MORE && tap <= 5;                // piece tap
         // ---------- phase 1 of the step ("other": issue, fragment fetch, halo transform) ----------
         // Counted waits: the raw halo piece of the latest issue window (always the newest VMEM operation of a wave,
         // issued AFTER the weights) may stay in flight -- it is consumed three steps later; everything older has landed.
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
         // issue window would make it wait for that window's weights)
         vec_t cur;
-        if (do_store) cur = raw[t];
+        if (do_store) cur = raw[tap & 1];
         asm volatile("" : "+v"(cur));  // pins the copy (and the compiler's vmcnt for it) here
         if (do_load && tap == 1) ab_store(abq, sAn);
         // issue window of the step: weights of the NEXT K-step, then one raw halo piece of the next chunk
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         if (wm == 1 && !(AB & 1) && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
-          raw[t] = load_piece(3 * g + t, csn);
+          raw[tap & 1] = load_piece(tap, csn);
         }
         // ---- fragments of k-piece 0 ----
         vec_t a[MI], b[NI];
@@ -334,9 +334,12 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
+            // k-pieces stay apart: otherwise the last weight fragment is re-requested INTO the register of the other one,
+            // i.e. only after the next k-piece's first four MFMAs, with its LDS latency exposed
+            __builtin_amdgcn_sched_barrier(0);
           }
         };
-        if (do_store) xform_store(3 * (g - 1) + t, cur, sAn);
+        if (do_store) xform_store(tap - 2, cur, sAn);
         // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
         unsigned long long tq2 = 0;
         if (AB & 256) { tq2 = __builtin_readcyclecounter(); pc_other += tq2 - tq1; }
