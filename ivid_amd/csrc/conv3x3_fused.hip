@@ -183,6 +183,28 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
   };
 
+  // the same transform in slices (development mode L: interleaved with the MFMAs of a k-piece): pair k of the piece
+  auto xform_pair = [&](int k, float* f, char* sAdst) {
+    const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
+    const f32x4 q = *(const f32x4*)(cf + k * AROW);
+    const f32x2 x = {f[2 * k], f[2 * k + 1]};
+    const f32x2 v = x * f32x2{q[0], q[1]} + f32x2{q[2], q[3]};
+    const f32x2 t = v * -1.4426950408889634f;
+    f32x2 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    d = d + 1.0f;
+    const f32x2 y = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f[2 * k] = y[0];
+    f[2 * k + 1] = y[1];
+  };
+  auto xform_finish = [&](int j, const float* f, char* sAdst) {
+    vec_t o = f32_to_vec<T>(f);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
+    u32x4 ob = __builtin_bit_cast(u32x4, o);
+    ob &= keep;
+    if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
+  };
+
   // ---- weight staging (as conv_igemm): thread owns 4 pieces of the [256][128 B] slab, rows 64 apart (same swizzle) ----
   const int b_row = tid >> 3;
   unsigned b_voff[4];  // rows past Cout are clamped: they produce columns the epilogue never stores
@@ -290,7 +312,12 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         // issue window of the step (both groups in phase 1): the lagging group stages the whole weight slab of the NEXT
         // K-step (global time = the leading group's MFMA phase: the stage it overwrites was read until the last barrier),
         // then every wave requests one raw halo piece of the next chunk
-        if (wm == 1 && !(AB & 1) && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        constexpr bool LOCK = (AB & 1024) != 0;   // development mode L: lockstep waves, one barrier per step, transform interleaved
+        if (LOCK) {
+          if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        } else if (wm == 1 && !(AB & 1) && (MORE || tap < 8)) {
+          issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
+        }
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
           raw[tap & 1] = load_piece(tap, csn);
@@ -301,6 +328,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
+        float fx[VE];
+        if (LOCK && do_store) vec_to_f32<T>(cur, fx);
         auto mma_block = [&]() {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
@@ -320,7 +349,27 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
             mma(2, 1);
             if (pf) a_next(2);
             mma(3, 1);
-            if (pf) {
+            if (LOCK && do_store) {
+              if (kk < VE / 2) xform_pair(kk, fx, sAn);
+              if (kk == 3) xform_finish(tap - 2, fx, sAn);
+            }
+            if (LOCK) {
+              if (pf) {
+                a_next(3);
+                b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
+              }
+              // one MFMA, then a slice of the other pipes: VALU / transcendental / LDS
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i >= 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            } else if (pf) {
               a_next(3);
               b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
               // pin the rotation: 4 MFMA, read, then (MFMA, read) x 4 (the last one 2 reads)
@@ -339,18 +388,29 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         };
-        if (do_store) xform_store(tap - 2, cur, sAn);
+        if (!LOCK && do_store) xform_store(tap - 2, cur, sAn);
+        if ((AB & 512) && do_store) xform_store(tap - 2, cur, sAn);   // development: double work per barrier interval
         // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
         unsigned long long tq2 = 0;
         if (AB & 256) { tq2 = __builtin_readcyclecounter(); pc_other += tq2 - tq1; }
-        if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else wait_vmcnt0();
-        __syncthreads();  // barrier Y
+        if (!LOCK) {
+          if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else wait_vmcnt0();
+          __syncthreads();  // barrier Y
+        }
         unsigned long long tq3 = 0;
         if (AB & 256) { tq3 = __builtin_readcyclecounter(); pc_bary += tq3 - tq2; }
         __builtin_amdgcn_sched_barrier(0);
         if (AB & 64) __builtin_amdgcn_s_setprio(1);
         mma_block();
+        if (AB & 512) {   // development: double work per barrier interval (results are garbage, timing only)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_block();
+        }
         if (AB & 64) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (AB & 256) pc_mma += __builtin_readcyclecounter() - tq3;
@@ -368,10 +428,10 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   wait_vmcnt0();
   unsigned long long cyc1 = 0;
   if (AB & 256) { ts[1] = wall_clock64(); cyc1 = __builtin_readcyclecounter(); }
-  if (wm == 1) __syncthreads();
+  if (!(AB & 1024) && wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
-  if (wm == 0) __syncthreads();  // the two wave groups are aligned again
+  if (!(AB & 1024) && wm == 0) __syncthreads();  // the two wave groups are aligned again
 
   // ---------------- optional skip phase: acc += x[tile pixels] . Wskip  (the ResBlock's 1x1 skip_connection on its raw
   // input x = cat(sk0, sk1)); a plain 2-stage LDS-DMA pipeline like conv_igemm with taps = 1: A stage = the tile's 256
@@ -606,6 +666,8 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
       case 8: return launch_fused<__bf16, 8>(a, (hipStream_t)stream);
       case 64: return launch_fused<__bf16, 64>(a, (hipStream_t)stream);
       case 256: return launch_fused<__bf16, 256>(a, (hipStream_t)stream);
+      case 512: return launch_fused<__bf16, 512>(a, (hipStream_t)stream);
+      case 1024: return launch_fused<__bf16, 1024>(a, (hipStream_t)stream);
       default: break;
     }
   }
