@@ -437,7 +437,7 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   hipStream_t s = (hipStream_t)stream;
   if ((tile_cfg & 7) == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
     const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
-    tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1));
+    tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 384) ? 2 : 1));
   }
   if (stats) {  // a statistics block must not straddle two images
     const int gran = (tile_cfg & 7) == 3 ? 32 : 64;
@@ -462,7 +462,7 @@ extern "C" int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_c
   if (cfg == 0) {
     const long long M = (long long)N * H * W;
     const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
-    cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 512) ? 2 : 1);
+    cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 384) ? 2 : 1);
   }
   return cfg == 3 ? 32 : 64;
 }
