@@ -205,6 +205,11 @@ def main():
             "algorithmic_gflop_per_launch_avg": round(conv["flop"] / conv["n"] / 1e9, 2),
             "algorithmic_bytes_per_launch_avg": round(conv["byt"] / conv["n"], 0),
             "share_of_forward_time": round(conv["ms"] / total_ms, 4),
+            # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
+            # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
+            # profiles/r01_mfma_power.txt) -- the ceiling this kernel family actually works under:
+            "power_limited_mfma_peak_random_operands": 1606.0 if a.precision == "bf16" else None,
+            "frac_of_power_limited_peak": round(ach / 1606.0, 4) if a.precision == "bf16" else None,
         }
         result["kernel_time_ms_per_forward"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items())}
         if os.environ.get("IVID_BENCH_LAYERS"):  # per-launch table for kernel tuning (not part of the bench line)
