@@ -70,8 +70,11 @@ def pipeline_part():
     seeds = list(range(bs))
     classes = [s % 1000 for s in seeds]
 
+    g = torch.Generator(device="cuda").manual_seed(1)
+    nf = (lambda shape: torch.randn(tuple(shape), device="cuda", generator=g)) if os.environ.get("NOISE") == "global" else None
+
     def run():
-        return list(sample_all(fu, fc, seeds, su, sc, views, classes=classes, guidance=3.0, batchsize=bs))
+        return list(sample_all(fu, fc, seeds, su, sc, views, classes=classes, guidance=3.0, batchsize=bs, noise_fn=nf))
     run()                                   # warm-up: plans, graphs
     torch.cuda.synchronize()
     t0 = time.perf_counter()
