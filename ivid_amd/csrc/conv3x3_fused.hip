@@ -254,8 +254,36 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     ab_store(q0, sA0);
     wait_vmcnt0();
     __syncthreads();  // coefficients of chunk 0 visible
+    // all six pieces in lockstep: they share the channel piece, hence the coefficients (read once), and their 6 x VE/2
+    // independent exp/rcp chains overlap instead of running one piece after the other (pipeline fill, no MFMA yet)
+    {
+      const char* cf = sA0 + 128 + cpc * (VE / 2) * AROW;
+      f32x4 q[VE / 2];
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) xform_store(j, rawp[j], sA0);
+      for (int k = 0; k < VE / 2; ++k) q[k] = *(const f32x4*)(cf + k * AROW);
+      float f[PIECES][VE];
+#pragma unroll
+      for (int j = 0; j < PIECES; ++j) vec_to_f32<T>(rawp[j], f[j]);
+#pragma unroll
+      for (int k = 0; k < VE / 2; ++k) {
+        f32x2 v[PIECES], d[PIECES];
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+          v[j] = f32x2{f[j][2 * k], f[j][2 * k + 1]} * f32x2{q[k][0], q[k][1]} + f32x2{q[k][2], q[k][3]};
+          const f32x2 t = v[j] * -1.4426950408889634f;
+          d[j] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        }
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+          d[j] = d[j] + 1.0f;
+          const f32x2 y = v[j] * f32x2{__builtin_amdgcn_rcpf(d[j][0]), __builtin_amdgcn_rcpf(d[j][1])};
+          f[j][2 * k] = y[0];
+          f[j][2 * k + 1] = y[1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PIECES; ++j) xform_finish(j, f[j], sA0);
+    }
   }
 
   f32x16 acc[MI][NI];
