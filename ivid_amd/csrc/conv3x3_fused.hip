@@ -13,13 +13,19 @@
 //   A operand : per 128-byte channel chunk, the (8+2) x (32+2) pixel HALO of the tile is read raw from HBM/L2 into
 //               registers (one 16-byte piece = 8 bf16 channels of one pixel per lane), transformed ONCE
 //               y = silu(x*a + b) with the per-(image, channel) GroupNorm/FiLM coefficients (gn_finalize's output),
-//               zeroed outside the image (the conv pads the ACTIVATED tensor), and written to a double-buffered,
-//               XOR-swizzled LDS image.  The 9 taps then read their fragments from that image at shifted rows.
+//               zeroed outside the image (the conv pads the ACTIVATED tensor), and written to a double-buffered LDS
+//               image with one 144-byte row per halo pixel (odd 16-byte stride: conflict-free for any row shift, so a
+//               fragment address is one per-lane base + a compile-time offset).  The 9 taps read their fragments from
+//               that image at shifted rows.
 //   B operand : the [256 cout x 128 B] weight slab of (chunk, tap) streams through a 2-stage LDS ring with
-//               global_load_lds, exactly as in conv_igemm.hip.
-//   schedule  : K-step = (chunk, tap); taps are unrolled, each tap issues the raw load of ONE halo piece of the NEXT
-//               chunk and, two taps later (right after the step's barrier, when everything older in flight has landed),
-//               transforms + stores it: at most 3 pieces (12 VGPRs) are in flight and the VALU work is spread evenly.
+//               global_load_lds (XOR-swizzled as in conv_igemm.hip).
+//   schedule  : K-step = (chunk, tap), taps unrolled.  The two wave groups (waves w and w+4 share a SIMD) run ping-pong,
+//               one barrier apart: while one executes its 32 MFMAs the other fetches its fragments, transforms one halo
+//               piece of the NEXT chunk (requested two taps earlier, 2 x 4 VGPRs in flight) and -- the lagging group
+//               only -- issues the whole weight DMA of the next step.  Details and the hazard analysis sit next to the
+//               loop; measurements (ablations, phase cycle counters, power ceiling) in profiles/ and DESIGN.md.
+//   optional  : the ResBlock's 1x1 skip_connection on the raw block input, accumulated into the same tile after the
+//               3x3 K-steps (ivid_conv3x3_gn_skip).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
