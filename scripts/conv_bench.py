@@ -16,6 +16,7 @@ SHAPES = [  # (H, Cin, Cout, taps)
     (128, 256, 256, 9), (128, 512, 256, 9), (128, 512, 256, 1), (64, 256, 256, 9), (64, 768, 256, 9), (32, 512, 512, 9),
     (32, 1280, 512, 9), (32, 512, 1536, 1), (16, 768, 768, 9), (16, 1792, 768, 9), (8, 1024, 1024, 9), (8, 2048, 1024, 9),
     (16, 1024, 1024, 9), (16, 768, 2304, 1), (8, 1024, 3072, 1), (32, 512, 512, 1), (16, 768, 768, 1), (8, 1024, 1024, 1),   # 12..17
+    (128, 128, 128, 9), (128, 256, 128, 9), (64, 128, 128, 9),   # 18..20: the small / SR models' 128-channel layers
 ]
 
 
