@@ -175,6 +175,13 @@ def main():
         prof = plan.profile_eager()
         fam = {}
         for name, args, ms in prof:
+            if name == "ivid_conv3x3_gn_out":   # the output head: same family, its own argument list
+                (_dt, _s, c_, _ab, _w, _b, _o, n_, h_, w_, co_) = args
+                f = fam.setdefault("ivid_conv3x3_gn", dict(ms=0.0, n=0, flop=0.0, byt=0.0))
+                f["ms"] += ms; f["n"] += 1
+                f["flop"] += 2.0 * n_ * h_ * w_ * co_ * 9 * c_
+                f["byt"] += float(n_ * h_ * w_ * c_ * (2 if _dt == 1 else 4) + n_ * h_ * w_ * co_ * 4)
+                continue
             fused = name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip")
             f = fam.setdefault("ivid_conv3x3_gn" if fused else name, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
             f["ms"] += ms

@@ -79,6 +79,13 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
                          int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
                          const void* skip_weight, void* stream);
 
+/* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
+ * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].
+ *   src NHWC [N,H,W,C] in `dtype`; ab fp32 [N][C][2]; weight [Cout][9][C] in `dtype`; 1 <= Cout <= 16; W % 32 == 0, H % 8 == 0.
+ * Reads the 1 GiB input once instead of three times (gn_apply round trip + nine shifted re-reads). */
+int ivid_conv3x3_gn_out(int dtype, const void* src, int C, const float* ab, const void* weight, const float* bias, float* out,
+                        int N, int H, int W, int Cout, void* stream);
+
 /* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
  * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).
  *   partial: fp32 [N][nchunks][C0+C1][2]; nchunks = ivid_gn_num_chunks(H*W). */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
     "ivid_conv3x3_gn": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_conv3x3_gn_out": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ivid_conv3x3_gn_skip": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp,
                                    vp, i32, vp, i32, vp, vp]),
     "ivid_gn_num_chunks": (i32, [i32]),

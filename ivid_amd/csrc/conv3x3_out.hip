@@ -1,0 +1,244 @@
+// Output convolution of the UNet, fused:  GroupNorm-apply -> SiLU -> Conv2d 3x3 with a handful of output channels,
+// written as fp32 NCHW (adm.py:483-487 `self.out` = GroupNorm32, SiLU, zero_module(conv 3x3, model_channels -> out_channels);
+// adm.py:565-566 casts back to the input dtype = fp32).
+//
+// With Cout = 4 the layer has 0.05 % of the model's FLOPs but read its 1 GiB input three times through the generic path
+// (gn_apply: read + write; conv_igemm: nine L2 re-reads of the activated copy).  Here the input is read once:
+//   tile      : 8 x 32 output pixels of one image; 8 waves, wave w = image row w (one 32-pixel MFMA fragment)
+//   A operand : the halo image of conv3x3_fused.hip (one 144-byte LDS row per halo pixel, transformed y = silu(x*a + b)
+//               while it is staged, coefficients parked in the row pads)
+//   B operand : ALL 9 taps of a 128-byte channel chunk at once: [tap][Cout][128 B] = 4.5 KB for Cout = 4; the 32-lane
+//               fragment reads row min(lane, Cout-1), so the padded accumulator columns hold copies that are never stored
+//   schedule  : two barriers per CHUNK (not per tap): 36 MFMAs per wave between them; the 6 halo pieces of the next chunk
+//               are requested before the MFMAs and transformed in lockstep after them (16 accumulator VGPRs leave room
+//               to keep all six in flight)
+// The kernel is bound by the halo transform and the input stream, not by the matrix pipe.
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+struct OutArgs {
+  const char* src;
+  const float* ab;     // [N][C][2]
+  const char* w;       // [Cout][9][C]
+  const float* bias;   // [Cout] or null
+  float* out;          // fp32 NCHW [N][Cout][H][W]
+  int C, N, H, W, Cout;
+  int tiles_x, tiles_y, ntiles_total;
+};
+
+template <typename T> struct MmaO;
+template <> struct MmaO<__bf16> {
+  static __device__ __forceinline__ void run(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MmaO<float> {
+  static __device__ __forceinline__ void run(const f32x4& a, const f32x4& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+
+constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, HROWS = HH_ * HW_;
+constexpr int NT = 512, AROW = 144, A_BYTES = HROWS * AROW, PIECES = (HROWS + 63) / 64;
+constexpr int MAXCO = 16;                              // output channels the weight stages are sized for
+constexpr int B_BYTES = 9 * MAXCO * 128;               // one chunk, all taps
+constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;   // 134,784
+
+template <typename T>
+__global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
+  typedef typename Elem<T>::vec vec_t;
+  constexpr int VE = Elem<T>::VE;
+  constexpr int BKE = 128 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sA0 = smem;
+  char* const sB0 = smem + 2 * A_BYTES;
+
+  const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
+  const int tx = tile % p.tiles_x;
+  int rest = tile / p.tiles_x;
+  const int ty = rest % p.tiles_y;
+  const int img = rest / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = p.C, Cout = p.Cout;
+  const int chunks = C / BKE;
+
+  // ---- halo pieces of this thread (as conv3x3_fused.hip) ----
+  const int cpc = tid & 7, hrow0 = tid >> 3;
+  int pix[PIECES];
+  unsigned okbits = 0;
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    const int hrow = j * 64 + hrow0;
+    const int hy = hrow / HW_, hx = hrow - hy * HW_;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    const bool ok = hrow < HROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    pix[j] = ok ? y * p.W + x : 0;
+    okbits |= (ok ? 1u : 0u) << j;
+  }
+  const int st_lds = hrow0 * AROW + cpc * 16;
+  const bool act5 = hrow0 < HROWS - 5 * 64;
+  const char* const src_img = p.src + (size_t)img * p.H * p.W * C * sizeof(T);
+  const int cb = C * (int)sizeof(T);
+  const float* abn = p.ab + (size_t)img * C * 2;
+
+  auto load_pieces = [&](int ch, vec_t* raw) {
+    const char* base = src_img + (size_t)ch * 128;
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) raw[j] = *(const vec_t*)(base + (size_t)(__umul24(pix[j], cb) + cpc * 16));
+  };
+  auto ab_load = [&](int ch) -> f32x4 {
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && lane < BKE / 2) q = *(const f32x4*)(abn + (size_t)ch * BKE * 2 + lane * 4);
+    return q;
+  };
+  auto ab_store = [&](const f32x4& q, char* sAdst) {
+    if (wave == 0 && lane < BKE / 2) *(f32x4*)(sAdst + lane * AROW + 128) = f32x4{q[0], q[2], q[1], q[3]};
+  };
+  // all six pieces in lockstep: shared coefficients (same channel piece), overlapping exp / rcp chains
+  auto xform_all = [&](const vec_t* raw, char* sAdst) {
+    const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
+    f32x4 q[VE / 2];
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) q[k] = *(const f32x4*)(cf + k * AROW);
+    float f[PIECES][VE];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) vec_to_f32<T>(raw[j], f[j]);
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) {
+      f32x2 v[PIECES], d[PIECES];
+#pragma unroll
+      for (int j = 0; j < PIECES; ++j) {
+        v[j] = f32x2{f[j][2 * k], f[j][2 * k + 1]} * f32x2{q[k][0], q[k][1]} + f32x2{q[k][2], q[k][3]};
+        const f32x2 t = v[j] * -1.4426950408889634f;
+        d[j] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      }
+#pragma unroll
+      for (int j = 0; j < PIECES; ++j) {
+        d[j] = d[j] + 1.0f;
+        const f32x2 y = v[j] * f32x2{__builtin_amdgcn_rcpf(d[j][0]), __builtin_amdgcn_rcpf(d[j][1])};
+        f[j][2 * k] = y[0];
+        f[j][2 * k + 1] = y[1];
+      }
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f[j]));
+      ob &= (okbits >> j) & 1 ? 0xffffffffu : 0u;
+      if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
+    }
+  };
+  // weights of chunk ch, all taps: piece q = (tap * Cout + row) * 8 + pc  ->  LDS byte 16 q (lane-linear per wave)
+  const int npieces_b = 9 * Cout * 8;
+  auto issue_b = [&](int stage, int ch) {
+    for (int q0 = 0; q0 < npieces_b; q0 += NT) {   // wave-uniform trip count (<= 3)
+      const int q = q0 + tid;
+      if (q0 + wave * 64 < npieces_b) {             // whole waves past the end skip the DMA
+        const int qq = min(q, npieces_b - 1);       // idle lanes of the last wave re-read the last piece
+        const int pc = qq & 7, rt = qq >> 3;
+        const int tap = rt / Cout, row = rt - tap * Cout;
+        const unsigned voff = (unsigned)((((size_t)row * 9 + tap) * C + (size_t)ch * BKE) * sizeof(T)) + pc * 16;
+        glds16_s(p.w, voff, sB0 + stage * B_BYTES + (q0 + wave * 64) * 16);
+      }
+    }
+  };
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int a_base = (wave * HW_ + frow) * AROW + fhalf * 16;          // top-left tap, k-piece 0
+  const int b_base = min(frow, Cout - 1) * 128 + fhalf * 16;
+
+  // ---------------- prologue ----------------
+  vec_t raw[PIECES];
+  {
+    const f32x4 q0 = ab_load(0);
+    issue_b(0, 0);
+    load_pieces(0, raw);
+    ab_store(q0, sA0);
+    wait_vmcnt0();
+    __syncthreads();
+    xform_all(raw, sA0);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int ch = 0; ch < chunks; ++ch) {
+    const bool more = ch + 1 < chunks;
+    wait_vmcnt0();
+    __syncthreads();  // halo(ch) complete, weights(ch) landed, everyone done with the other buffers
+    const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
+    const char* bptr = sB0 + (ch & 1) * B_BYTES + b_base;
+    char* sAn = sA0 + ((ch + 1) & 1) * A_BYTES;
+    f32x4 abq = {0.f, 0.f, 0.f, 0.f};
+    if (more) {
+      issue_b((ch + 1) & 1, ch + 1);
+      abq = ab_load(ch + 1);
+      load_pieces(ch + 1, raw);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const vec_t a = *(const vec_t*)(aptr + ((tap / 3) * HW_ + tap % 3) * AROW + kk * 32);
+        const vec_t b = *(const vec_t*)(bptr + tap * Cout * 128 + kk * 32);
+        MmaO<T>::run(a, b, acc);
+      }
+    }
+    if (more) {
+      ab_store(abq, sAn);
+      wait_vmcnt0();
+      __syncthreads();  // coefficients of chunk ch+1 visible (its halo image is not read by anyone yet)
+      xform_all(raw, sAn);
+    }
+  }
+
+  // ---------------- epilogue: accumulator column = output channel, 16 registers = 16 of the row's 32 pixels ----------------
+  const int co = frow;
+  if (co < Cout) {
+    const float bs = p.bias ? p.bias[co] : 0.f;
+    float* o = p.out + (((size_t)img * Cout + co) * p.H + (y0 + wave)) * p.W + x0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // registers 4j..4j+3 = pixels 8j + 4*fhalf + 0..3
+      const f32x4 v = {acc[4 * j] + bs, acc[4 * j + 1] + bs, acc[4 * j + 2] + bs, acc[4 * j + 3] + bs};
+      *(f32x4*)(o + 8 * j + 4 * fhalf) = v;
+    }
+  }
+}
+
+template <typename T> int launch_out(const OutArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_out_kernel<T>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return ivid_set_error("conv3x3_gn_out: hipFuncSetAttribute", e);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles_total), dim3(NT), LDS_BYTES, stream, a);
+  return ivid_check_launch("conv3x3_gn_out");
+}
+
+}  // namespace
+
+extern "C" int ivid_conv3x3_gn_out(int dtype, const void* src, int C, const float* ab, const void* weight, const float* bias,
+                                   float* out, int N, int H, int W, int Cout, void* stream) {
+  const int esz = dtype == IVID_F32 ? 4 : 2;
+  const int bke = 128 / esz;
+  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv3x3_gn_out: bad dtype", hipSuccess);
+  if (C <= 0 || C % bke) return ivid_set_error("conv3x3_gn_out: channels must be a multiple of the K-step", hipSuccess);
+  if (Cout <= 0 || Cout > MAXCO) return ivid_set_error("conv3x3_gn_out: 1..16 output channels (use ivid_conv3x3_gn otherwise)", hipSuccess);
+  if (W % TW || H % TH) return ivid_set_error("conv3x3_gn_out: needs W % 32 == 0 and H % 8 == 0", hipSuccess);
+  if (!src || !ab || !weight || !out) return ivid_set_error("conv3x3_gn_out: null argument", hipSuccess);
+  if ((size_t)H * W * C * esz >= ((size_t)1 << 31) || (size_t)Cout * 9 * C * esz >= ((size_t)1 << 32))
+    return ivid_set_error("conv3x3_gn_out: image or weight matrix too large for 32-bit offsets", hipSuccess);
+  OutArgs a;
+  a.src = (const char*)src; a.ab = ab; a.w = (const char*)weight; a.bias = bias; a.out = out;
+  a.C = C; a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+  a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_total = N * a.tiles_x * a.tiles_y;
+  if (dtype == IVID_BF16) return launch_out<__bf16>(a, (hipStream_t)stream);
+  return launch_out<float>(a, (hipStream_t)stream);
+}

@@ -379,11 +379,19 @@ class UNetPlan:
                 stash.append(h)
         assert not stash
         # ---- head: GN + SiLU + conv3x3 -> fp32 NCHW (adm.py:565-566) ----
-        act = self._gn(h, None, "out.0", None, 0, 1)
-        self._free(h)
-        self._conv(self.dtype, act.ptr, sp.final_c, None, 0, "out.2", self.out.data_ptr(), None, 0, 1, n, S, S,
-                   sp.out_channels, 9)
-        self._free(act)
+        if (self.fuse_conv and S % 32 == 0 and sp.out_channels <= 16 and sp.final_c % (128 // self.esz) == 0
+                and os.environ.get("IVID_NO_FUSED_HEAD", "0") != "1"):
+            ab = self._gn_coeffs(h, None, "out.0", None)      # one kernel: the input is read once
+            self._rec("ivid_conv3x3_gn_out", self.dtype, h.ptr, sp.final_c, ab.data_ptr(), self.w["out.2.weight"].data_ptr(),
+                      self.w["out.2.bias"].data_ptr(), self.out.data_ptr(), n, S, S, sp.out_channels)
+            self.arena.put(ab)
+            self._free(h)
+        else:
+            act = self._gn(h, None, "out.0", None, 0, 1)
+            self._free(h)
+            self._conv(self.dtype, act.ptr, sp.final_c, None, 0, "out.2", self.out.data_ptr(), None, 0, 1, n, S, S,
+                       sp.out_channels, 9)
+            self._free(act)
 
     # ---- execution ----
     def _enqueue(self, stream):

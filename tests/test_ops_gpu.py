@@ -256,6 +256,37 @@ def test_stem_im2col_then_1x1_equals_the_3x3_stem_conv(cin, dtype):
     assert e < G.tol(dtype, 2e-6, 4e-3), e
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [("head_c128_co4", 2, 16, 64, 128, 4), ("head_c64_co3", 1, 8, 32, 64, 3),
+                                  ("head_c256_co16", 1, 16, 32, 256, 16)], ids=lambda c: c[0])
+def test_conv3x3_gn_out_head(case, dtype):
+    """The UNet head (adm.py:483-487, 565-566): GN-apply + SiLU + conv3x3 to a few channels, fp32 NCHW out, one kernel."""
+    name, N, H, W, Cc, Cout = case
+    if dtype == 0 and Cc % 32:
+        pytest.skip("K-step")
+    L = G.lib()
+    s_ = sum(map(ord, name)) % 1000
+    x = common.seeded_randn(s_, N, Cc, H, W)
+    a = 0.5 + 0.5 * torch.rand(N, Cc, generator=torch.Generator().manual_seed(s_))
+    b = 0.3 * common.seeded_randn(s_ + 2, N, Cc)
+    w = common.seeded_randn(s_ + 3, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    bias = common.seeded_randn(s_ + 4, Cout) * 0.1
+    act = G.rounded(F.silu(G.rounded(x, dtype) * a[:, :, None, None] + b[:, :, None, None]), dtype)
+    ref = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1).float()
+    dx = G.to_nhwc(x, dtype)
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    bd = bias.cuda()
+    out = torch.full((N, Cout, H, W), float("nan"), device="cuda", dtype=torch.float32)
+    L.call("ivid_conv3x3_gn_out", dtype, L.ptr(dx), Cc, L.ptr(ab), L.ptr(wp), L.ptr(bd), L.ptr(out), N, H, W, Cout, G.stream())
+    torch.cuda.synchronize()
+    got = out.cpu()
+    e = common.rel_l2(got, ref)
+    G.report(f"conv3x3_gn_out/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e)
+    assert torch.isfinite(got).all()
+    assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
+
+
 def test_conv3x3_gn_is_bitwise_repeatable_at_full_occupancy():
     """Race screen for the ping-pong schedule (counted vmcnt, LDS-DMA ordered by hand): every CU busy for several rounds,
     the same launch repeated must give bit-identical outputs and statistics, and must match a tiny-grid launch of the same
