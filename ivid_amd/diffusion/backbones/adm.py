@@ -175,6 +175,8 @@ class AdmUnet2d(nn.Module):
             assert self.has_null_class or bool(torch.all(classes >= 0)), "this model does not have a null class"
         assert x.shape[1:] == (self.in_channels, self.image_size, self.image_size), \
             f"expected input [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
+        if x.shape[0] == 0:   # empty batch: what the reference's torch ops return (no launch)
+            return x.new_zeros((0, self.out_channels, self.image_size, self.image_size), dtype=torch.float32)
         out = self.plan(x.shape[0], False).run(x.float(), times, classes, self.use_graph)
         return out.clone()
 

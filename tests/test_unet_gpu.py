@@ -267,3 +267,18 @@ def test_full_size_properties_large_bf16_bs64():
     xg = C.seeded_randn(104, 1, 4, 128, 128)
     e = m.forward_cfg(xg.cuda(), torch.full((1,), 999).cuda(), torch.tensor([7]).cuda())[0].cpu()
     G.report("unet/large128_bs64_bf16", golden_row_rel_l2=C.rel_l2(e, g["eps"]))
+
+
+def test_edge_batches_empty_and_single():
+    """Ragged / degenerate batches: an empty batch returns an empty fp32 tensor like the reference's torch ops would, a
+    batch of one matches the oracle (tile tails everywhere: 1 image = 4 tiles of the fused kernel at 32^2)."""
+    m, sd = build(C.MINI, 3, "fp32")
+    S = C.MINI["image_size"]
+    e = m(torch.zeros(0, 4, S, S, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"), None)
+    assert e.shape == (0, 4, S, S) and e.dtype == torch.float32
+    x = C.seeded_randn(77, 1, 4, S, S)
+    t = torch.full((1,), 321, dtype=torch.long)
+    cls = torch.tensor([5])
+    got = m(x.cuda(), t.cuda(), cls.cuda()).cpu()
+    ref = adm_oracle.unet_forward(sd, C.MINI, x, t, cls)
+    assert C.rel_l2(got, ref) < PARITY_BAR
