@@ -65,7 +65,8 @@ int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg);
  * out = bias + conv3x3( pad0( up?( silu( cat(src0,src1) * a + b ) ) ) ) (+ residual), with a,b = ab[n][c][0..1] from
  * ivid_gn_finalize{,2}.  The activated tensor never exists in HBM: the (8+2)x(32+2) pixel halo of each tile is
  * transformed once while it is staged into LDS.  up = 1: src is [N,H/2,W/2,C] (Upsample2d inside an `up` ResBlock).
- * res_mode: 0 none, 1 same size, 2 nearest-x2-upsampled residual [N,H/2,W/2,Cout].
+ * res_mode: 0 none, 1 same size, 2 nearest-x2-upsampled residual [N,H/2,W/2,Cout], 3 2x2-average-pooled residual
+ *           [N,2H,2W,Cout] (the identity skip of a `down` ResBlock seen through Downsample2d, adm.py:115-117,203-208).
  * stats: as ivid_conv2d with 128-pixel blocks (4 image rows x 32 columns; H*W/128 blocks per image). */
 int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                     const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,

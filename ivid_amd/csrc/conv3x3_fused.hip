@@ -596,6 +596,20 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
           vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += rv[e];
+        } else if (p.res_mode == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)
+          float sacc[VE];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) sacc[e] = 0.f;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const size_t pix = ((size_t)img * (p.H << 1) + 2 * y + (d >> 1)) * (p.W << 1) + 2 * (x0 + row) + (d & 1);
+            float rv[VE];
+            vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
         }
         const vec_t ov = f32_to_vec<T>(v);
         *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
@@ -670,7 +684,7 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   if (W % TW || H % TH) return ivid_set_error("conv3x3_gn: needs W % 32 == 0 and H % 8 == 0 (use ivid_gn_apply + ivid_conv2d otherwise)", hipSuccess);
   if (Cout % ve) return ivid_set_error("conv3x3_gn: Cout must be a multiple of 16 bytes", hipSuccess);
   if (up && ((H | W) & 1)) return ivid_set_error("conv3x3_gn: upsample needs even H,W", hipSuccess);
-  if (res_mode < 0 || res_mode > 2 || (res_mode && !res)) return ivid_set_error("conv3x3_gn: bad residual", hipSuccess);
+  if (res_mode < 0 || res_mode > 3 || (res_mode && !res)) return ivid_set_error("conv3x3_gn: bad residual", hipSuccess);
   if (!ab) return ivid_set_error("conv3x3_gn: ab missing", hipSuccess);
   if (skipC0 < 0 || skipC1 < 0 || skipC0 % bke || skipC1 % bke || (skipC0 == 0 && skipC1 > 0))
     return ivid_set_error("conv3x3_gn: skip channels must be multiples of the K-step", hipSuccess);

@@ -264,7 +264,8 @@ class UNetPlan:
         so = op.res_out
         # the fused kernel's tile is 256 output channels wide: at Cout <= 128 (the small / SR models' first levels) half of
         # its MFMAs would be padding and gn_apply + the 128x128-tile igemm is faster (measured 1.29 vs 0.86 + 0.2 ms)
-        fused = self.fuse_conv and op.mode != "down" and so % 32 == 0 and op.cout > 128
+        fused2 = self.fuse_conv and so % 32 == 0 and op.cout > 128      # out_layers conv: its input is at the output size
+        fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         h1 = self._new(n, so, op.cout, stats=True)
         if fused:
             ab1 = self._gn_coeffs(x, skip, op.prefix + ".in_layers.0", None)
@@ -275,14 +276,14 @@ class UNetPlan:
             self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
                        op.cout, 9, out_act=h1)
             self._free(act1)
-        if fused:
+        if fused2:
             ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off)
         else:
             act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
             self._free(h1)
         out = self._new(n, so, op.cout, stats=True)
         kstep = 128 // self.esz
-        if (fused and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
+        if (fused2 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
                 and (skip is None or skip.c % kstep == 0)):
             # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
             # residual round trip)
@@ -302,7 +303,7 @@ class UNetPlan:
             assert skip is None
             r = None
             res_ptr, res_mode = x.ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
-        if fused:
+        if fused2:
             self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode)
             self.arena.put(ab2)
             self._free(h1)

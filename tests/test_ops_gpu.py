@@ -114,6 +114,7 @@ FUSED_CASES = [
     ("up_res_up", 2, 32, 32, 64, 0, 64, 1, 2),
     ("wide_2ntiles", 1, 16, 64, 64, 0, 512, 0, 1),
     ("tall_cout320", 1, 40, 32, 128, 0, 320, 0, 0),
+    ("down_res_avgpool", 2, 16, 32, 64, 0, 96, 0, 3),
 ]
 
 
@@ -137,6 +138,8 @@ def test_conv3x3_gn_fused(case, dtype):
         res = common.seeded_randn(s + 5, N, Cout, H, W)
     elif res_mode == 2:
         res = common.seeded_randn(s + 5, N, Cout, H // 2, W // 2)
+    elif res_mode == 3:
+        res = common.seeded_randn(s + 5, N, Cout, 2 * H, 2 * W)
     # reference
     x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
     act = F.silu(x * a[:, :, None, None] + b[:, :, None, None])
@@ -148,6 +151,8 @@ def test_conv3x3_gn_fused(case, dtype):
         ref = ref + G.rounded(res, dtype).double()
     elif res_mode == 2:
         ref = ref + F.interpolate(G.rounded(res, dtype).double(), scale_factor=2, mode="nearest")
+    elif res_mode == 3:
+        ref = ref + F.avg_pool2d(G.rounded(res, dtype).double(), 2)
     ref = ref.float()
     d0 = G.to_nhwc(x0, dtype)
     d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
