@@ -6,7 +6,6 @@ Bars: fp32 (parity) mode <= 1e-3 relative as BASELINE.json's north_star states (
 bf16 (perf) mode is reported in gpurun_out/parity_report.json with a loose sanity bound — it cannot
 meet 1e-3 (the reference's own fp16 torso is 1.6e-3 from fp32).
 """
-import numpy as np
 import pytest
 import torch
 
