@@ -7,16 +7,27 @@ synthetic seeded weights (no checkpoints offline), synthetic x_T.  One bench "st
 both guidance branches (2 UNet forwards at bs 64, executed as one stacked batch-128 forward replayed from a
 hipGraph) + the fused CFG/DDIM update kernel.  `value` = UNet bs-64 forwards per second summed over all ranks.
 
-Multi-GPU (`torchrun ... bench.py --gpus N`): sample-parallel — every rank runs its own batch of 64 (weak scaling),
-weights are synthesised on rank 0 and broadcast once over RCCL; no collective inside the timed region.
+Multi-GPU: `python bench.py --gpus N` launches ITSELF as N ranks (torch.distributed.run, one process per GPU, RCCL);
+under an external torchrun it uses the ranks it is given and refuses a WORLD_SIZE that differs from --gpus.
+Sample-parallel: every rank runs its own batch of 64 (weak scaling), weights are synthesised on rank 0 and
+broadcast once over RCCL; no collective inside the timed region.  `ranks_seen` lists the (rank, device) pairs an
+all_gather collected.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (conv_igemm, the dominant kernel family: algorithmic
-FLOPs of every launch in one forward / HIP-event time of those launches; plus the whole-forward figure),
-`cpu_baseline` (the fp32 CPU oracle timed on the host cores of rank 0 on a bounded sample).
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline          the dominant kernel (conv3x3_fused_kernel): algorithmic FLOPs of its launches in one forward /
+                    HIP-event time of those launches (events on the plan's stream), against the dense bf16 MFMA peak
+  roofline_kernels  the same for every kernel family of the forward (weakest visible in the line itself)
+  parity_mode       the same step timed in the precision mode whose measured deviation from the reference is <= 1e-3
+                    (bf16x3: split-bf16 operands, 3 MFMAs per product), with `rel_l2_vs_reference` measured in THIS run
+                    against the committed reference output tests/golden/large128_fwd.npz
+  cpu_baseline      the reference (if /root/reference is importable: kind "reference") or the fp32 CPU oracle
+                    (kind "port") timed on the host cores of rank 0 on a bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +36,53 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
+# flops (its 3 MFMAs per product are overhead, not work)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}
+ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
-GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--model", default="large", choices=["large", "small", "sr256"])
+    ap.add_argument("--precision", default="bf16", choices=sorted(DTYPE_CODE))
+    ap.add_argument("--parity-precision", default="bf16x3", choices=sorted(DTYPE_CODE),
+                    help="second, parity-grade mode timed beside the headline ('none' via --no-parity-mode)")
+    ap.add_argument("--guidance", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--launcher-dry-run", action="store_true",
+                    help="initialise the ranks, all_gather (rank, device), print ranks_seen and exit (CPU/gloo test of the launcher)")
+    return ap.parse_args(argv)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without torchrun: re-exec under torch.distributed.run, one process per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, IVID_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------- algorithmic work of a recorded launch ----------------
 def conv_flops(args):
     """Algorithmic FLOPs of one ivid_conv2d launch from its recorded arguments (2 x MACs)."""
     (dtype, _s0, c0, _s1, c1, _w, _b, _o, _r, _rm, _om, n, h, w, cout, taps, _tc, _st) = args
@@ -47,7 +98,7 @@ def fused_flops(args):
 
 def conv_bytes(args, fused):
     """Algorithmic HBM bytes of one convolution launch: every input element, weight and residual read once, every output
-    written once (compulsory traffic; the PMC-measured figure is reported beside it as `traffic`)."""
+    written once (compulsory traffic)."""
     skc = 0
     if fused:
         (dtype, _s0, c0, _s1, c1, _ab, up, _w, _b, _o, r, rm, n, h, w, cout, _st) = args[:17]
@@ -56,7 +107,7 @@ def conv_bytes(args, fused):
     else:
         (dtype, _s0, c0, _s1, c1, _w, _b, _o, r, rm, om, n, h, w, cout, taps, _tc, _st) = args
         up = 0
-    esz = 2 if dtype == 1 else 4
+    esz = ESZ[dtype]
     src = n * (h >> up) * (w >> up) * (c0 + c1) * esz
     out = n * h * w * cout * (4 if om else esz)
     res = 0 if not rm else (out if rm == 1 else (out // 4 if rm == 2 else out * 4))
@@ -68,38 +119,107 @@ def attn_flops(args):
     return 2.0 * (2.0 * heads * t * t * 64) * n
 
 
-def pmc_traffic():
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+def attn_bytes(args):
+    (dtype, _q, _o, n, t, heads) = args
+    return float(n * t * heads * 64 * 4 * ESZ[dtype])     # q, k, v read once, o written once
+
+
+def cached_pmc_traffic():
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         return round(float(json.load(open(f))["conv_family_hbm_bytes_per_launch"]), 0)
     except Exception:
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--model", default="large", choices=["large", "small"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--guidance", type=float, default=0.5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-breakdown", action="store_true")
-    a = ap.parse_args()
+KERNEL_OF = {"ivid_conv3x3_gn": "conv3x3_fused_kernel", "ivid_conv3x3_gn_skip": "conv3x3_fused_kernel",
+             "ivid_conv2d": "conv_igemm_kernel", "ivid_attention": "attn_kernel", "ivid_conv3x3_gn_out": "conv3x3_out_kernel"}
 
+
+def kernel_table(prof, precision):
+    """[(c_abi_name, args, ms)] of one eager forward -> per-kernel {ms, launches, flop, bytes} and the ms of everything else."""
+    fam, other = {}, {}
+    for name, args, ms in prof:
+        k = KERNEL_OF.get(name)
+        if k is None:
+            other[name] = other.get(name, 0.0) + ms
+            continue
+        f = fam.setdefault(k, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
+        f["ms"] += ms
+        f["n"] += 1
+        if name == "ivid_conv2d":
+            fl, _ = conv_flops(args)
+            f["flop"] += fl
+            f["byt"] += conv_bytes(args, False)
+        elif name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip"):
+            f["flop"] += fused_flops(args)
+            f["byt"] += conv_bytes(args, True)
+        elif name == "ivid_attention":
+            f["flop"] += attn_flops(args)
+            f["byt"] += attn_bytes(args)
+        else:   # output head
+            (_dt, _s, c_, _ab, _w, _b, _o, n_, h_, w_, co_) = args
+            f["flop"] += 2.0 * n_ * h_ * w_ * co_ * 9 * c_
+            f["byt"] += float(n_ * h_ * w_ * c_ * ESZ[_dt] + n_ * h_ * w_ * co_ * 4)
+    return fam, other
+
+
+def roofline_entry(kernel, f, peak_tf, total_ms, batch_n):
+    """One `roofline` object.  MFMA kernels: algorithmic TFLOP/s vs the dense peak.  The 4-channel output head is bound by
+    its input stream: algorithmic GB/s vs the HBM peak."""
+    if kernel == "conv3x3_out_kernel":
+        ach = f["byt"] / (f["ms"] * 1e-3) / 1e9
+        e = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4)}
+    else:
+        ach = f["flop"] / (f["ms"] * 1e-3) / 1e12
+        e = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+             "frac": round(ach / peak_tf, 4)}
+    e.update({"traffic": None, "launches_per_forward": f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 4),
+              "algorithmic_gflop_per_launch_avg": round(f["flop"] / f["n"] / 1e9, 2),
+              "algorithmic_bytes_per_launch_avg": round(f["byt"] / f["n"], 0),
+              "share_of_forward_time": round(f["ms"] / total_ms, 4), "forward_batch": batch_n})
+    return e
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
     import common as C
     from ivid_amd import parallel
+
+    rank, world = parallel.init_from_env()
+    if world != max(1, a.gpus):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE {world}: launch with matching values "
+                         f"(or run `python bench.py --gpus {a.gpus}` and let it start the ranks itself)")
+    have_gpu = torch.cuda.is_available()
+    local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    dev = torch.device("cuda", local) if have_gpu else torch.device("cpu")
+    if have_gpu:
+        torch.cuda.set_device(dev)
+    # who is here: one (rank, device index) pair per process, collected with a collective on the data-path backend
+    seen = parallel.gather_scalars(rank * 1000 + (local + 1 if have_gpu else 0))
+    ranks_seen = [[int(v) // 1000, int(v) % 1000 - 1] for v in seen]   # device -1 = no GPU (CPU dry run)
+    if a.launcher_dry_run:
+        if rank == 0:
+            print(json.dumps({"launcher": "ok", "n_gpus": world, "ranks_seen": ranks_seen,
+                              "backend": dist.get_backend() if world > 1 else None,
+                              "self_launched": os.environ.get("IVID_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    assert have_gpu, "bench.py needs an MI355X (ivid_amd has no CPU execution path)"
+
     from ivid_amd.diffusion import frameworks, samplers
     from ivid_amd.diffusion.backbones import AdmUnet2d
 
-    rank, world = parallel.init_from_env()
-    assert world == max(1, a.gpus) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
-    torch.cuda.set_device(dev)
-
-    margs = dict(C.LARGE128 if a.model == "large" else C.SMALL128)
+    margs = dict({"large": C.LARGE128, "small": C.SMALL128, "sr256": C.SR256}[a.model])
+    S = margs["image_size"]
     schema = C.schema_for(margs)
     sd = C.synth_weights(margs, 0) if rank == 0 else None
     sd = parallel.broadcast_state_dict(schema, sd, device=dev)       # one RCCL broadcast over xGMI
@@ -108,13 +228,18 @@ def main():
     del sd
     model = model.to(dev).eval()
     has_cls = margs["num_classes"] is not None
-    fw = (frameworks.ClassifierFreeGuidance(model, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
-          if has_cls else frameworks.GaussianDiffusion(model, timesteps=1000, beta_schedule="linear"))
-    smp = samplers.DdimSampler(fw)
     B = a.batch
-    x = C.seeded_randn(123 + rank, B, 4, 128, 128).to(dev)
     classes = (torch.arange(B) % 1000).to(dev) if has_cls else None
     kw = dict(strength=a.guidance) if has_cls else {}
+    if a.model == "sr256":   # SuperResCFG: the low-res views are the condition (sr_cfg.py:23-36)
+        fw = frameworks.SuperResCFG(model, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+        kw["y"] = C.seeded_randn(321 + rank, B, 4, S // 2, S // 2).clamp(-1, 1).to(dev)
+    elif has_cls:
+        fw = frameworks.ClassifierFreeGuidance(model, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    else:
+        fw = frameworks.GaussianDiffusion(model, timesteps=1000, beta_schedule="linear")
+    smp = samplers.DdimSampler(fw)
+    x = C.seeded_randn(123 + rank, B, 4, S, S).to(dev)
     fwd_per_step = 2 if has_cls and a.guidance > 0 else 1
     # DDIM 50-step schedule of config 2: (1000,980) ... (20,0); the bench walks it cyclically
     pairs = [(20 * (i + 1), 20 * i) for i in reversed(range(50))]
@@ -129,96 +254,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    xi = x
-    for i in range(a.warmup):
-        xi = step(i, xi)
-    if a.warmup < 2:  # the first call is eager, the second captures the hipGraph: keep both out of the timed region
-        for i in range(2 - a.warmup):
+    def timed(steps, warmup):
+        """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize fences; max over ranks."""
+        xi = x
+        for i in range(max(warmup, 2)):   # the first call is eager, the second captures the hipGraph: never timed
             xi = step(i, xi)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        xi = step(a.warmup + i, xi)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(xi).all(), "non-finite samples"
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            xi = step(warmup + i, xi)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert torch.isfinite(xi).all(), "non-finite samples"
+        return dt
 
+    dt = timed(a.steps, a.warmup)
     fwd_s = fwd_per_step * a.steps * world / dt
     gflop = GFLOP_PER_SAMPLE_FWD[a.model]
     peak = PEAK_TFLOPS[a.precision]
     job_tflops = fwd_s * B * gflop / 1e3
+    res_name = {"large": "rgbd_imagenet_adm_128_large_cfg uncond", "small": "rgbd_singlecategory_adm_128_small uncond",
+                "sr256": "rgbd_imagenet_adm_256_128_small_sr (SuperResCFG, 128->256)"}[a.model]
 
     result = {
         "metric": "denoise-steps/sec (UNet fwd/s) at 128x128 RGBD bs=64",
         "value": round(fwd_s, 4),
-        "unit": "UNet fwd/s (bs=%d, 128x128 RGBD)" % B,
+        "unit": "UNet fwd/s (bs=%d, %dx%d RGBD)" % (B, S, S),
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic (seeded random-init weights, N(0,1) x_T)",
-        "config": {"workload": "rgbd_imagenet_adm_128_%s_cfg uncond, DDIM 50-step schedule, bs=%d per GPU, CFG=%.2f "
+        "config": {"workload": "%s, DDIM 50-step schedule, bs=%d per GPU, CFG=%.2f "
                                "(1 step = %d UNet forwards stacked into one batch-%d hipGraph forward + fused DDIM update)"
-                               % (a.model, B, a.guidance, fwd_per_step, B * fwd_per_step),
+                               % (res_name, B, a.guidance if has_cls else 0.0, fwd_per_step, B * fwd_per_step),
                    "parallelism": "sample-parallel x%d (no collective in the denoise loop)" % world},
+        "ranks_seen": ranks_seen,
         "denoise_steps_per_s": round(a.steps * world / dt, 4),
         "sample_fwd_per_s": round(fwd_s * B, 2),
         "job_tflops": round(job_tflops, 2),
         "mfma_roofline_frac_whole_step": round(job_tflops / world / peak, 4),
     }
 
+    # ---- deviation of a mode from the REFERENCE, measured in this run: the committed golden output of the live reference
+    #      (tests/golden/large128_fwd.npz, generated by tests/golden/make_golden.py from /root/reference) ----
+    golden = {"large": ("large128_fwd", C.LARGE128, 4), "small": ("small128_fwd", C.SMALL128, 3)}.get(a.model)
+
+    def rel_l2_vs_reference(precisions):
+        if golden is None:
+            return {}
+        name, gargs, seed = golden
+        g = C.load_golden(name)
+        gm = AdmUnet2d(**gargs, precision=precisions[0])
+        gm.load_state_dict(C.synth_weights(gargs, seed), strict=True)
+        gm = gm.to(dev).eval()
+        xg = C.seeded_randn(100 + seed, 1, gargs["in_channels"], S, S).to(dev)
+        tg = torch.full((1,), int(g["t"]), dtype=torch.long, device=dev)
+        out = {}
+        for prec in precisions:
+            gm.set_precision(prec)
+            if "classes" in g:
+                ec, eu = gm.forward_cfg(xg, tg, torch.from_numpy(g["classes"]).to(dev))
+                out[prec] = max(C.rel_l2(ec.cpu(), g["eps"]), C.rel_l2(eu.cpu(), g["eps_uncond"]))
+            else:
+                out[prec] = C.rel_l2(gm(xg, tg, None).cpu(), g["eps"])
+        del gm
+        return out
+
     if rank == 0 and not a.no_kernel_breakdown:
         plan = model.plan(B, stacked=(fwd_per_step == 2))
         prof = plan.profile_eager()
-        fam = {}
-        for name, args, ms in prof:
-            if name == "ivid_conv3x3_gn_out":   # the output head: same family, its own argument list
-                (_dt, _s, c_, _ab, _w, _b, _o, n_, h_, w_, co_) = args
-                f = fam.setdefault("ivid_conv3x3_gn", dict(ms=0.0, n=0, flop=0.0, byt=0.0))
-                f["ms"] += ms; f["n"] += 1
-                f["flop"] += 2.0 * n_ * h_ * w_ * co_ * 9 * c_
-                f["byt"] += float(n_ * h_ * w_ * c_ * (2 if _dt == 1 else 4) + n_ * h_ * w_ * co_ * 4)
-                continue
-            fused = name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip")
-            f = fam.setdefault("ivid_conv3x3_gn" if fused else name, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
-            f["ms"] += ms
-            f["n"] += 1
-            if name == "ivid_conv2d":
-                fl, dt_ = conv_flops(args)
-                if dt_ == (1 if a.precision == "bf16" else 0):
-                    f["flop"] += fl
-                f["byt"] += conv_bytes(args, False)
-            elif fused:
-                f["flop"] += fused_flops(args)
-                f["byt"] += conv_bytes(args, True)
-            elif name == "ivid_attention":
-                f["flop"] += attn_flops(args)
-        total_ms = sum(f["ms"] for f in fam.values())
-        conv = dict(fam["ivid_conv2d"])
-        if "ivid_conv3x3_gn" in fam:  # the two MFMA convolution kernels together = 97 % of the model's FLOPs
-            for k in ("ms", "n", "flop", "byt"):
-                conv[k] += fam["ivid_conv3x3_gn"][k]
-        ach = conv["flop"] / (conv["ms"] * 1e-3) / 1e12
-        result["roofline"] = {
-            "kernel": "conv3x3_fused_kernel + conv_igemm_kernel (all %d convolution launches of one batch-%d forward)" % (conv["n"], plan.n),
-            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            # HBM bytes per conv-family launch from the PMC passes of THIS command (rocprofv3 --pmc FETCH_SIZE /
-            # WRITE_SIZE, gfx950-corrected; scripts/gpu_pmc_bench.sh -> profiles/pmc_traffic.json); null if not collected
-            "traffic": pmc_traffic(),
-            "avg_launch_ms": round(conv["ms"] / conv["n"], 4),
-            "algorithmic_gflop_per_launch_avg": round(conv["flop"] / conv["n"] / 1e9, 2),
-            "algorithmic_bytes_per_launch_avg": round(conv["byt"] / conv["n"], 0),
-            "share_of_forward_time": round(conv["ms"] / total_ms, 4),
-            # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
-            # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
-            # profiles/r01_mfma_power.txt) -- the ceiling this kernel family actually works under:
-            "power_limited_mfma_peak_random_operands": 1606.0 if a.precision == "bf16" else None,
-            "frac_of_power_limited_peak": round(ach / 1606.0, 4) if a.precision == "bf16" else None,
-        }
-        result["kernel_time_ms_per_forward"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items())}
+        fam, other = kernel_table(prof, a.precision)
+        total_ms = sum(f["ms"] for f in fam.values()) + sum(other.values())
+        order = sorted(fam, key=lambda k: -fam[k]["ms"])
+        entries = [roofline_entry(k, fam[k], peak, total_ms, plan.n) for k in order]
+        dom = dict(entries[0])
+        # HBM bytes per launch of the convolution kernels from the PMC passes of this command are NOT collected in this
+        # run (rocprofv3 --pmc is a separate invocation: scripts/gpu_pmc_bench.sh -> profiles/pmc_traffic.json)
+        ct = cached_pmc_traffic()
+        if ct is not None and a.precision == "bf16" and a.model == "large":
+            dom["traffic_cached"] = {"value": ct, "from": "profiles/pmc_traffic.json (conv kernels, bytes per launch, earlier run)"}
+        # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
+        # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
+        # profiles/r01_mfma_power.txt) -- the ceiling this kernel actually works under:
+        if a.precision in ("bf16", "fp16") and dom["bound"] == "mfma":
+            dom["power_limited_mfma_peak_random_operands"] = 1606.0
+            dom["frac_of_power_limited_peak"] = round(dom["achieved"] / 1606.0, 4)
+        result["roofline"] = dom
+        result["roofline_kernels"] = entries
+        kt = {k: round(v["ms"], 3) for k, v in sorted(fam.items())}
+        kt.update({k: round(v, 3) for k, v in sorted(other.items())})
+        result["kernel_time_ms_per_forward"] = kt
         if os.environ.get("IVID_BENCH_LAYERS"):  # per-launch table for kernel tuning (not part of the bench line)
             rows = []
             for name, args, ms in prof:
@@ -229,48 +358,100 @@ def main():
                 elif name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip"):
                     fl = fused_flops(args)
                     rows.append(dict(fused=1, n=args[12], h=args[13], cin=args[2] + args[4], cout=args[15], taps=9, up=args[6],
-                                     res=args[11], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
-                elif name in ("ivid_gn_apply", "ivid_gn_partial", "ivid_attention"):
-                    rows.append(dict(op=name, args=[a for a in args if isinstance(a, int) and a < (1 << 32)], ms=round(ms, 4)))
+                                     res=args[11], skip=(args[18] + args[20]) if len(args) > 17 else 0, ms=round(ms, 4),
+                                     tflops=round(fl / ms / 1e9, 1)))
+                elif name in ("ivid_gn_apply", "ivid_gn_partial", "ivid_attention", "ivid_conv3x3_gn_out", "ivid_gn_finalize2"):
+                    rows.append(dict(op=name, args=[v for v in args if isinstance(v, int) and v < (1 << 32)], ms=round(ms, 4)))
             with open(os.environ["IVID_BENCH_LAYERS"], "w") as f:
                 json.dump(rows, f, indent=0)
         result["forward_ms_eager_events"] = round(total_ms, 3)
 
+    # ---- the parity-grade mode, timed beside the headline on the same workload (every rank, same fences) ----
+    if not a.no_parity_mode and a.parity_precision != a.precision:
+        pp = a.parity_precision
+        model.set_precision(pp)
+        psteps = max(2, min(a.steps, 5))
+        pdt = timed(psteps, 2)
+        pf = fwd_per_step * psteps * world / pdt
+        ptf = pf * B * gflop / 1e3
+        result["parity_mode"] = {"dtype": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
+                                 "ms_per_step": round(1e3 * pdt / psteps, 3), "job_tflops": round(ptf, 2),
+                                 "frac": round(ptf / world / PEAK_TFLOPS[pp], 4),
+                                 "frac_note": "algorithmic FLOPs / dense bf16 MFMA peak (the 3 MFMAs per product are overhead)"}
+        model.set_precision(a.precision)
+        if rank == 0:
+            dev_tab = rel_l2_vs_reference([a.precision, pp])
+            if dev_tab:
+                result["rel_l2_vs_reference"] = round(dev_tab[a.precision], 6)
+                result["parity_mode"]["rel_l2_vs_reference"] = round(dev_tab[pp], 8)
+                result["parity_mode"]["reference_output"] = "tests/golden/%s.npz (live reference, fp32 CPU)" % golden[0]
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N = 1 only (a host-side figure)
-        # the oracle (a CPU restatement of the reference forward, pinned to it bit-for-bit by tests/golden) on the
-        # host cores: 1 warm-up + 2 timed forwards at bs 2, fp32
-        from oracle import adm_oracle
-        # threads actually usable by this process (cgroup/affinity), capped: torch's CPU kernels stop scaling (and
-        # oversubscribe badly) far below the 256 logical cores of the GPU host
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except Exception:
-            avail = os.cpu_count()
-        ncores = max(1, min(avail, int(os.environ.get("IVID_CPU_BASELINE_THREADS", "32"))))
-        torch.set_num_threads(ncores)
-        sd_cpu = C.synth_weights(margs, 0)
-        xb = C.seeded_randn(5, 2, 4, 128, 128)
-        tb = torch.full((2,), 500, dtype=torch.long)
-        cb = torch.tensor([1, 2]) if has_cls else None
-        adm_oracle.unet_forward(sd_cpu, margs, xb, tb, cb)
-        c0 = time.perf_counter()
-        nrep = 0
-        while nrep < 2 or (time.perf_counter() - c0 < 10.0 and nrep < 16):   # >= 10 s of CPU work, bounded
-            adm_oracle.unet_forward(sd_cpu, margs, xb, tb, cb)
-            nrep += 1
-        cdt = time.perf_counter() - c0
-        s_fwd = nrep * 2 / cdt
-        result["cpu_baseline"] = {"value": round(s_fwd / B, 5), "unit": result["unit"], "cores": ncores, "kind": "port",
-                                  "sample": "oracle UNet forward (fp32 torch CPU, %s model): %d timed forwards at bs 2 in %.1f s = "
-                                            "%.2f sample-fwd/s, scaled to bs-%d forwards" % (a.model, nrep, cdt, s_fwd, B),
-                                  "sample_fwd_per_s": round(s_fwd, 3)}
-        result["speedup_vs_cpu"] = round(fwd_s / (s_fwd / B), 1)
+        result["cpu_baseline"] = cpu_baseline(C, margs, has_cls, a.model, B, result["unit"])
+        result["speedup_vs_cpu"] = round(fwd_s / result["cpu_baseline"]["value"], 1)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(C, margs, has_cls, model_name, B, unit):
+    """The reference forward on the host cores: the reference's own AdmUnet2d imported from /root/reference when that
+    tree exists (this container; kind "reference"), else the oracle (a CPU restatement pinned to it bit-for-bit by
+    tests/golden; kind "port").  1 warm-up + >= 2 timed fp32 forwards at bs 4, >= 10 s of CPU work."""
+    import torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count()
+    # threads actually usable by this process (cgroup/affinity), capped: torch's CPU kernels stop scaling (and
+    # oversubscribe badly) far below the 256 logical cores of the GPU host
+    ncores = max(1, min(avail, int(os.environ.get("IVID_CPU_BASELINE_THREADS", "32"))))
+    torch.set_num_threads(ncores)
+    sd_cpu = C.synth_weights(margs, 0)
+    S = margs["image_size"]
+    bs = 4
+    xb = C.seeded_randn(5, bs, margs["in_channels"], S, S)
+    tb = torch.full((bs,), 500, dtype=torch.long)
+    cb = torch.tensor([1, 2, 3, 4]) if has_cls else None
+    kind, fwd = "port", None
+    ref_root = "/root/reference"
+    if os.path.isdir(os.path.join(ref_root, "diffusion", "backbones")):
+        try:
+            sys.path.insert(0, ref_root)
+            from diffusion.backbones import AdmUnet2d as RefUnet   # noqa: E402  (torch + numpy only, SURVEY.md §8c)
+            rm = RefUnet(**margs).eval()
+            rm.load_state_dict(sd_cpu, strict=True)
+            kind = "reference"
+
+            def fwd():
+                with torch.no_grad():
+                    return rm(xb, tb, cb)
+        except Exception:
+            kind, fwd = "port", None
+        finally:
+            if ref_root in sys.path:
+                sys.path.remove(ref_root)
+    if fwd is None:
+        from oracle import adm_oracle
+
+        def fwd():
+            return adm_oracle.unet_forward(sd_cpu, margs, xb, tb, cb)
+    fwd()
+    c0 = time.perf_counter()
+    nrep = 0
+    while nrep < 2 or (time.perf_counter() - c0 < 10.0 and nrep < 16):   # >= 10 s of CPU work, bounded
+        fwd()
+        nrep += 1
+    cdt = time.perf_counter() - c0
+    s_fwd = nrep * bs / cdt
+    what = "reference AdmUnet2d (/root/reference, fp32 torch CPU)" if kind == "reference" else "oracle UNet forward (fp32 torch CPU)"
+    return {"value": round(s_fwd / B, 5), "unit": unit, "cores": ncores, "kind": kind,
+            "sample": "%s, %s model: %d timed forwards at bs %d in %.1f s = %.2f sample-fwd/s, scaled to bs-%d forwards"
+                      % (what, model_name, nrep, bs, cdt, s_fwd, B),
+            "sample_fwd_per_s": round(s_fwd, 3)}
 
 
 if __name__ == "__main__":

@@ -10,8 +10,9 @@
  *   - every kernel is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises;
  *   - return value 0 = ok, nonzero = error; ivid_last_error() gives the message; never aborts;
  *   - activations inside the UNet are NHWC ("pixel-major") of dtype IVID_F32 (parity mode, exact
- *     fp32 MFMA) or IVID_BF16 (perf mode, bf16 MFMA with fp32 accumulate); the model boundary is
- *     fp32 NCHW exactly like the reference (adm.py:557,565-566).
+ *     fp32 MFMA), IVID_BF16 / IVID_F16 (16-bit storage and MFMA operands, fp32 accumulate) or
+ *     IVID_BF16X3 (fp32 storage, split-bf16 MFMA); the model boundary is fp32 NCHW exactly like the
+ *     reference (adm.py:557,565-566).
  */
 #ifndef IVID_HIP_H
 #define IVID_HIP_H
@@ -20,8 +21,13 @@
 extern "C" {
 #endif
 
-#define IVID_F32 0
-#define IVID_BF16 1
+#define IVID_F32 0     /* fp32 storage, exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode, ~1e-6 vs the reference */
+#define IVID_BF16 1    /* bf16 storage + bf16 MFMA, fp32 accumulate: perf mode (~8e-3 on the large model) */
+#define IVID_F16 2     /* fp16 storage + fp16 MFMA, fp32 accumulate: the reference's `use_fp16` torso (backbones/utils.py:6-13) */
+#define IVID_BF16X3 3  /* fp32 storage; MFMA operands split into bf16 hi + lo, 3 bf16 MFMAs per product (a_hi*b_hi +
+                        * a_hi*b_lo + a_lo*b_hi), fp32 accumulate: <= 1e-3 parity at MFMA speed.  Conv weights are
+                        * pre-split by the host: per 8 input channels 16 bytes of hi followed by 16 bytes of lo, i.e. a
+                        * weight row has the byte size of an fp32 row (see ivid_conv2d) */
 
 /* ---- runtime ---- */
 const char* ivid_last_error(void);
@@ -42,7 +48,9 @@ int ivid_event_destroy(void* ev);
  * out[n,y,x,co] = bias[co] + sum_{tap,c} cat(src0,src1)[n,y+dy,x+dx,c] * weight[co][tap][c]  (+ residual)
  *   src0/src1 : NHWC [N,H,W,C0] / [N,H,W,C1] (C1 = 0, src1 = NULL when there is no skip concat,
  *               adm.py:563 torch.cat is never materialised); C0, C1 multiples of 64 (bf16) / 32 (f32)
- *   weight    : [Cout][taps][C0+C1], dtype as activations (repacked from [Cout,Cin,3,3] by the host)
+ *   weight    : [Cout][taps][C0+C1], dtype as activations (repacked from [Cout,Cin,3,3] by the host); IVID_BF16X3: the same
+ *               row order with every 8 consecutive K values stored as 8 x bf16 hi then 8 x bf16 lo (hi = bf16(w) RNE,
+ *               lo = bf16(w - hi)) — 32 bytes per 8 values, i.e. the byte size of the fp32 row; C0, C1 multiples of 32
  *   bias      : fp32 [Cout] or NULL
  *   res_mode  : 0 none; 1 add res[N,H,W,Cout]; 2 add nearest-x2-upsampled res[N,H/2,W/2,Cout];
  *               3 add 2x2-avg-pooled res[N,2H,2W,Cout]  (ResBlock2d skip through x_upd, adm.py:203-208,222)
@@ -83,6 +91,7 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].
  *   src NHWC [N,H,W,C] in `dtype`; ab fp32 [N][C][2]; weight [Cout][9][C] in `dtype`; 1 <= Cout <= 16; W % 32 == 0, H % 8 == 0.
+ *   IVID_BF16X3: runs the exact-fp32 kernel (src is fp32 anyway, the layer is 0.05 % of the FLOPs): weight is PLAIN fp32.
  * Reads the 1 GiB input once instead of three times (gn_apply round trip + nine shifted re-reads). */
 int ivid_conv3x3_gn_out(int dtype, const void* src, int C, const float* ab, const void* weight, const float* bias, float* out,
                         int N, int H, int W, int Cout, void* stream);

@@ -10,7 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IVID_HIP_LIB") or os.path.join(_HERE, "lib", "libivid_hip.so")   # override: A/B tuning builds
 
-F32, BF16 = 0, 1
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3   # include/ivid_hip.h IVID_*
+PRECISIONS = {"fp32": F32, "bf16": BF16, "fp16": F16, "bf16x3": BF16X3}
+
+
+def esz(dtype):
+    """Bytes per stored activation element (BF16X3 stores fp32)."""
+    return 4 if dtype in (F32, BF16X3) else 2
 
 vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_longlong, C.c_void_p
 

@@ -27,6 +27,10 @@ template <> struct AttnCfg<__bf16> {
   static constexpr int RB = 128;  // bytes per K row
   static __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 };
+template <> struct AttnCfg<_Float16> {
+  static constexpr int RB = 128;
+  static __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+};
 template <> struct AttnCfg<float> {
   static constexpr int RB = 256;
   static __device__ __forceinline__ int swz(int row) { return row & 15; }
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
   constexpr int TILE_BYTES = KVB * RB;      // one K (or V) tile
   constexpr int KPIECES = KVB * PPR;
   constexpr int KK = HD * (int)sizeof(T) / 32;  // piece pairs along d: 4 (bf16) / 8 (fp32)
-  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr bool IS_BF16 = sizeof(T) == 2;   // either 16-bit type: 32x32x16 MFMA, V transposed in LDS
+  typedef T t16x4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
   char* sK = smem;
   char* sV = smem + TILE_BYTES;
@@ -93,11 +98,11 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
       for (int i = 0; i < KPIECES / NT; ++i) {
         const int p = i * NT + tid;
         const int kv = p / PPR, d0 = (p - kv * PPR) * 8;
-        const bf16x8 v = *(const bf16x8*)(base + (size_t)(kv0 + kv) * rowstride + 2 * HD * sizeof(T) + d0 * 2);
+        const vec_t v = *(const vec_t*)(base + (size_t)(kv0 + kv) * rowstride + 2 * HD * sizeof(T) + d0 * 2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = d0 + e;
-          *(__bf16*)(sV + d * 128 + (((kv >> 2) ^ ((d >> 1) & 15)) << 3) + (kv & 3) * 2) = v[e];
+          *(T*)(sV + d * 128 + (((kv >> 2) ^ ((d >> 1) & 15)) << 3) + (kv & 3) * 2) = v[e];
         }
       }
     }
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
       for (int kk = 0; kk < KK; ++kk) {
         const vec_t kf = *(const vec_t*)(sK + row * RB + (((2 * kk + hf) ^ sw) << 4));
         if constexpr (IS_BF16) {
-          s[kvh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kvh], 0, 0, 0);
+          MmaT<T>::run(kf, qf[kk], s[kvh]);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) s[kvh] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[kk][j], s[kvh], 0, 0, 0);
@@ -156,24 +161,24 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
       for (int kvh = 0; kvh < 2; ++kvh)
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
-          bf16x8 pf;
+          vec_t pf;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kvh][8 * mm + e];
+          for (int e = 0; e < 8; ++e) pf[e] = (T)s[kvh][8 * mm + e];
           // element e of lane-half hf is kv = kvh*32 + 16*mm + 8*(e>>2) + 4*hf + (e&3)
           const int u0 = (kvh * 32 + 16 * mm + 4 * hf) >> 2;  // 8-byte unit of e = 0..3; e = 4..7 is unit u0+2
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
             const int d = dt * 32 + fq;
             const int sw = (d >> 1) & 15;
-            const bf16x4 lo = *(const bf16x4*)(sV + d * 128 + ((u0 ^ sw) << 3));
-            const bf16x4 hi = *(const bf16x4*)(sV + d * 128 + (((u0 + 2) ^ sw) << 3));
-            bf16x8 vf;
+            const t16x4 lo = *(const t16x4*)(sV + d * 128 + ((u0 ^ sw) << 3));
+            const t16x4 hi = *(const t16x4*)(sV + d * 128 + (((u0 + 2) ^ sw) << 3));
+            vec_t vf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               vf[e] = lo[e];
               vf[4 + e] = hi[e];
             }
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            MmaT<T>::run(vf, pf, o[dt]);
           }
         }
     } else {
@@ -200,10 +205,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
     for (int g = 0; g < 4; ++g) {
       const int d = dt * 32 + 8 * g + 4 * hf;
       if constexpr (IS_BF16) {
-        bf16x4 w;
+        t16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (__bf16)(o[dt][4 * g + e] * inv);
-        *(bf16x4*)(orow + d * 2) = w;
+        for (int e = 0; e < 4; ++e) w[e] = (T)(o[dt][4 * g + e] * inv);
+        *(t16x4*)(orow + d * 2) = w;
       } else {
         f32x4 w;
 #pragma unroll
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
 }  // namespace
 
 extern "C" int ivid_attention(int dtype, const void* qkv, void* out, int N, int T, int heads, void* stream) {
-  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("attention: bad dtype", hipSuccess);
+  if (!ivid_esz(dtype)) return ivid_set_error("attention: bad dtype", hipSuccess);
   if (T <= 0 || T % 64) return ivid_set_error("attention: T must be a multiple of 64", hipSuccess);
   hipStream_t s = (hipStream_t)stream;
   const bool four = (T % 128) == 0;
@@ -236,7 +241,9 @@ extern "C" int ivid_attention(int dtype, const void* qkv, void* out, int N, int 
     }
 #endif
     if (four) LAUNCH(__bf16, 4); else LAUNCH(__bf16, 2);
-  } else {
+  } else if (dtype == IVID_F16) {
+    if (four) LAUNCH(_Float16, 4); else LAUNCH(_Float16, 2);
+  } else {   // IVID_F32 and IVID_BF16X3 (fp32 storage): exact fp32 MFMA
     if (four) LAUNCH(float, 4); else LAUNCH(float, 2);
   }
 #undef LAUNCH

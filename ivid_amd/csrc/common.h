@@ -13,6 +13,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Storage type of the split-bf16 ("bf16x3") precision mode: activations are plain fp32 in HBM; only the MFMA kernels
+// treat it differently (operands split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate).
+struct bf16x3_t { float v; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -26,6 +31,14 @@ template <> struct Elem<__bf16> {
   static constexpr int VE = 8;
   typedef bf16x8 vec;
 };
+template <> struct Elem<_Float16> {
+  static constexpr int VE = 8;
+  typedef f16x8 vec;
+};
+template <> struct Elem<bf16x3_t> {
+  static constexpr int VE = 4;
+  typedef f32x4 vec;
+};
 
 // 16-byte piece <-> fp32 lanes.
 template <typename T> __device__ __forceinline__ void vec_to_f32(const typename Elem<T>::vec& v, float* f);
@@ -36,6 +49,14 @@ template <> __device__ __forceinline__ void vec_to_f32<float>(const f32x4& v, fl
 template <> __device__ __forceinline__ void vec_to_f32<__bf16>(const bf16x8& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void vec_to_f32<_Float16>(const f16x8& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void vec_to_f32<bf16x3_t>(const f32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = v[i];
 }
 template <typename T> __device__ __forceinline__ typename Elem<T>::vec f32_to_vec(const float* f);
 template <> __device__ __forceinline__ f32x4 f32_to_vec<float>(const float* f) {
@@ -50,6 +71,53 @@ template <> __device__ __forceinline__ bf16x8 f32_to_vec<__bf16>(const float* f)
   for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];  // RNE (v_cvt_pk_bf16_f32)
   return v;
 }
+
+template <> __device__ __forceinline__ f16x8 f32_to_vec<_Float16>(const float* f) {
+  f16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (_Float16)f[i];  // RNE (v_cvt_pk_f16_f32); overflows to inf like the reference's .half()
+  return v;
+}
+template <> __device__ __forceinline__ f32x4 f32_to_vec<bf16x3_t>(const float* f) {
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = f[i];
+  return v;
+}
+
+// Split of 8 fp32 values into bf16 hi + bf16 lo (x = hi + lo up to 2^-17 |x|): the operand form of the bf16x3 mode.
+__device__ __forceinline__ void split_bf16x8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h0 = (__bf16)x0[i], h1 = (__bf16)x1[i];
+    hi[i] = h0;
+    hi[4 + i] = h1;
+    lo[i] = (__bf16)(x0[i] - (float)h0);
+    lo[4 + i] = (__bf16)(x1[i] - (float)h1);
+  }
+}
+
+// One MFMA "product" in each precision mode.  A and B use the same k permutation, so the sum is unchanged.
+template <typename T> struct MmaT;
+template <> struct MmaT<__bf16> {
+  static __device__ __forceinline__ void run(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MmaT<_Float16> {
+  static __device__ __forceinline__ void run(const f16x8& a, const f16x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MmaT<float> {
+  // one 16-byte piece per lane = 4 k-values; MFMA j pairs k=j of the low-lane piece with k=j of the high-lane piece
+  static __device__ __forceinline__ void run(const f32x4& a, const f32x4& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+template <typename T> struct IsSplit { static constexpr bool value = false; };
+template <> struct IsSplit<bf16x3_t> { static constexpr bool value = true; };
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence: these kernels are
 // HBM-bound only as long as the VALU work per 16-byte piece stays small

@@ -56,19 +56,6 @@ struct FusedArgs {
   int skC0, skC1;
 };
 
-template <typename T> struct Mma2;
-template <> struct Mma2<__bf16> {
-  static __device__ __forceinline__ void run(const bf16x8& a, const bf16x8& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma2<float> {
-  static __device__ __forceinline__ void run(const f32x4& a, const f32x4& b, f32x16& c) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
-  }
-};
-
 constexpr int TH = 8, TW = 32;             // output tile (pixels)
 constexpr int HW_ = TW + 2, HH_ = TH + 2;  // halo
 constexpr int HROWS = HH_ * HW_;           // 340 halo pixels
@@ -84,9 +71,7 @@ constexpr int PIECES = (HROWS + 63) / 64;  // halo pieces per thread (64 halo pi
 constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 163,456 of the CU's 163,840
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// AB: development ablation mask (always 0 in the product; -DIVID_DEV_ABLATE + IVID_FUSED_ABLATE select others):
-//     1 no weight re-streaming, 2 no halo pipeline, 4 no epilogue global traffic, 8 no MFMAs
-template <typename T, int AB = 0>
+template <typename T>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -97,8 +82,6 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BYTES;
 
-  unsigned long long ts[4];
-  if (AB & 256) ts[0] = wall_clock64();
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   // tile id -> (image, tile row, tile col, cout tile); cout tiles of one pixel tile are neighbours (shared A in L2)
   const int tn = tile % p.ntiles_n;
@@ -133,7 +116,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     pix[j] = ok ? ys * Ws + xs : 0;
     okbits |= (ok ? 1u : 0u) << j;
   }
-  const int st_lds = hrow0 * AROW + cpc * 16;   // piece j adds 64 j rows
+  // LDS byte of this thread's piece inside a halo row (piece j adds 64 j rows)
+  const int st_lds = hrow0 * AROW + (IsSplit<T>::value ? (cpc >> 1) * 32 + (cpc & 1) * 8 : cpc * 16);
   const bool act5 = hrow0 < HROWS - 5 * 64;     // piece 5 exists for the first 20 halo rows only
   // wave-uniform description of where channel chunk ch lives (src0 or the skip tensor src1): addresses are a
   // wave-uniform 64-bit base + a 32-bit lane offset (no 64-bit VALU arithmetic, no address VGPR pairs)
@@ -164,13 +148,40 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   auto ab_store = [&](const f32x4& q, char* sAdst) {
     if (wave == 0 && lane < BKE / 2) *(f32x4*)(sAdst + lane * AROW + 128) = f32x4{q[0], q[2], q[1], q[3]};
   };
-  // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction), zero outside the image
+  // store of one transformed halo piece (fp32 lanes f[VE]) into the halo image, zero outside the image.
+  // bf16x3: the piece is 4 channels; its bf16 hi / lo halves go to 8-byte slots of the hi piece (2g) and the lo piece
+  // (2g+1) of the 8-channel group g = cpc>>1 the MFMA fragments are read from.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto store_piece = [&](int j, const float* f, char* sAdst) {
+    const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
+    if constexpr (IsSplit<T>::value) {
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)f[e];
+        l[e] = (__bf16)(f[e] - (float)h[e]);
+      }
+      u32x2 hb = __builtin_bit_cast(u32x2, h), lb = __builtin_bit_cast(u32x2, l);
+      hb &= keep;
+      lb &= keep;
+      if (j < PIECES - 1 || act5) {
+        *(u32x2*)(sAdst + st_lds + j * 64 * AROW) = hb;
+        *(u32x2*)(sAdst + st_lds + j * 64 * AROW + 16) = lb;
+      }
+    } else {
+      u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f));
+      ob &= keep;
+      if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
+    }
+  };
+  // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction)
   auto xform_store = [&](int j, const vec_t& raw, char* sAdst) {
     const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
     float f[VE];
     vec_to_f32<T>(raw, f);
 #pragma unroll
-    for (int e = 0; e < ((AB & 32) ? 0 : VE); e += 2) {
+    for (int e = 0; e < VE; e += 2) {
       const f32x4 q = *(const f32x4*)(cf + (e / 2) * AROW);
       const f32x2 x = {f[e], f[e + 1]};
       const f32x2 v = x * f32x2{q[0], q[1]} + f32x2{q[2], q[3]};
@@ -181,34 +192,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       f[e] = y[0];
       f[e + 1] = y[1];
     }
-    vec_t o = f32_to_vec<T>(f);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
-    u32x4 ob = __builtin_bit_cast(u32x4, o);
-    ob &= keep;
-    if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
-  };
-
-  // the same transform in slices (development mode L: interleaved with the MFMAs of a k-piece): pair k of the piece
-  auto xform_pair = [&](int k, float* f, char* sAdst) {
-    const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
-    const f32x4 q = *(const f32x4*)(cf + k * AROW);
-    const f32x2 x = {f[2 * k], f[2 * k + 1]};
-    const f32x2 v = x * f32x2{q[0], q[1]} + f32x2{q[2], q[3]};
-    const f32x2 t = v * -1.4426950408889634f;
-    f32x2 d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-    d = d + 1.0f;
-    const f32x2 y = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f[2 * k] = y[0];
-    f[2 * k + 1] = y[1];
-  };
-  auto xform_finish = [&](int j, const float* f, char* sAdst) {
-    vec_t o = f32_to_vec<T>(f);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
-    u32x4 ob = __builtin_bit_cast(u32x4, o);
-    ob &= keep;
-    if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
+    store_piece(j, f, sAdst);
   };
 
   // ---- weight staging (as conv_igemm): thread owns 4 pieces of the [256][128 B] slab, rows 64 apart (same swizzle) ----
@@ -244,10 +228,13 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   const int frow = lane & 31, fhalf = lane >> 5;
   // weight fragment (ni = 0, k-piece 0) inside a stage; fragment ni adds 32 rows = 4096 B (same swizzle), k-piece kk
   // flips address bits 5-6:  ((2kk + fhalf) ^ sw) << 4  ==  ((fhalf ^ sw) << 4) ^ (kk << 5)
-  const int b_addr0 = (wn * WTN + frow) * 128 + ((fhalf ^ (((wn * WTN + frow) >> 1) & 7)) << 4);
+  // (bf16x3: piece = 4s + 2*fhalf + l for MFMA s = 0/1 and l = 0 hi / 1 lo  ->  base uses 2*fhalf, s flips bit 6, l bit 4)
+  constexpr int FH = IsSplit<T>::value ? 2 : 1;
+  const int b_addr0 = (wn * WTN + frow) * 128 + (((FH * fhalf) ^ (((wn * WTN + frow) >> 1) & 7)) << 4);
   // halo fragment base = (fragment 0, lane pixel, k-piece 0) for the TOP-LEFT tap; fragment mi adds mi halo rows of
   // pixels (HW_ each), tap (g, t) adds g*HW_ + t pixels, k-piece kk adds 32 B: all compile-time ds_read offsets
-  const int a_base = ((wm * 4) * HW_ + frow) * AROW + fhalf * 16;
+  // (bf16x3: halo row = [h0 l0 h1 l1 h2 l2 h3 l3] pieces of 8 channels; lane half picks 32 B, s adds 64 B, lo adds 16 B)
+  const int a_base = ((wm * 4) * HW_ + frow) * AROW + fhalf * 16 * FH;
 
   // ---------------- prologue: everything of (chunk 0, tap 0) in ONE memory round trip ----------------
   {
@@ -288,7 +275,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
       }
 #pragma unroll
-      for (int j = 0; j < PIECES; ++j) xform_finish(j, f[j], sA0);
+      for (int j = 0; j < PIECES; ++j) store_piece(j, f[j], sA0);
     }
   }
 
@@ -308,7 +295,6 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // two halves in OPPOSITE order: while one group transforms its halo piece (VALU + transcendental pipes) the other
   // owns the matrix pipe, then they swap; both meet at the next step's barrier.  Fragment registers rotate: a fragment
   // is re-requested for k-piece kk+1 right after its last MFMA of k-piece kk has been issued.
-  unsigned long long pc_other = 0, pc_mma = 0, pc_barx = 0, pc_bary = 0;   // development phase counters (AB & 256)
   auto chunk_body = [&](const int ch, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
@@ -321,19 +307,15 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int tap = 3 * g + t;
-        const bool do_store = !(AB & 2) && MORE && tap >= 2 && tap <= 7;   // piece tap-2, requested two taps ago
-        const bool do_load = !(AB & 2) && MORE && tap <= 5;                // piece tap
+        const bool do_store = MORE && tap >= 2 && tap <= 7;   // piece tap-2, requested two taps ago
+        const bool do_load = MORE && tap <= 5;                // piece tap
         // ---------- phase 1 of the step ("other": issue, fragment fetch, halo transform) ----------
         // Counted waits: the raw halo piece of the latest issue window (always the newest VMEM operation of a wave,
         // issued AFTER the weights) may stay in flight -- it is consumed three steps later; everything older has landed.
-        const bool prev_loaded = !(AB & 2) && MORE && tap >= 1 && tap <= 6;
-        unsigned long long tq0 = 0;
-        if (AB & 256) tq0 = __builtin_readcyclecounter();
+        const bool prev_loaded = MORE && tap >= 1 && tap <= 6;
         if (prev_loaded) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else wait_vmcnt0();
         __syncthreads();  // barrier X
-        unsigned long long tq1 = 0;
-        if (AB & 256) { tq1 = __builtin_readcyclecounter(); pc_barx += tq1 - tq0; }
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
@@ -342,112 +324,134 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         if (do_store) cur = raw[tap & 1];
         asm volatile("" : "+v"(cur));  // pins the copy (and the compiler's vmcnt for it) here
         if (do_load && tap == 1) ab_store(abq, sAn);
-        // issue window of the step: weights of the NEXT K-step, then one raw halo piece of the next chunk
         // issue window of the step (both groups in phase 1): the lagging group stages the whole weight slab of the NEXT
         // K-step (global time = the leading group's MFMA phase: the stage it overwrites was read until the last barrier),
         // then every wave requests one raw halo piece of the next chunk
-        constexpr bool LOCK = (AB & 1024) != 0;   // development mode L: lockstep waves, one barrier per step, transform interleaved
-        if (LOCK) {
-          if (!(AB & 1) && (MORE || tap < 8)) issue_b(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
-        } else if (wm == 1 && !(AB & 1) && (MORE || tap < 8)) {
-          issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
-        }
+        if (wm == 1 && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
           raw[tap & 1] = load_piece(tap, csn);
         }
-        // ---- fragments of k-piece 0 ----
-        vec_t a[MI], b[NI];
+        const char* const ap = aptr + (g * HW_ + t) * AROW;   // fragment mi adds mi halo rows of pixels
+        if constexpr (IsSplit<T>::value) {
+          // ---- bf16x3: the K-step is 32 channels = 2 MFMA k-blocks s; per block three products hi*hi, hi*lo, lo*hi.
+          //      Fragments rotate in place: a register is re-requested for its next use right after its last MFMA. ----
+          auto lda = [&](int mi, int sl) { return *(const bf16x8*)(ap + mi * HW_ * AROW + sl); };          // sl = 64 s + 16 l
+          auto ldb = [&](int ni, int sl) { return *(const bf16x8*)(sB0 + (b_off ^ sl) + ni * 4096); };
+          auto mm = [&](const bf16x8& a, const bf16x8& b, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); };
+          bf16x8 aH[MI], aL[MI], bH[NI], bL[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW);
+          for (int mi = 0; mi < MI; ++mi) aH[mi] = lda(mi, 0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
-        float fx[VE];
-        if (LOCK && do_store) vec_to_f32<T>(cur, fx);
-        auto mma_block = [&]() {
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const int xo = (kk + 1) << 5;
-            const bool pf = kk < 3;
-            auto mma = [&](int mi, int ni) {
-              if (AB & 8) asm volatile("" ::"v"(a[mi]), "v"(b[ni]));
-              else Mma2<T>::run(a[mi], b[ni], acc[mi][ni]);
-            };
-            auto a_next = [&](int mi) { a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW + (kk + 1) * 32); };
-            mma(0, 0); mma(1, 0); mma(2, 0); mma(3, 0);
-            if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
-            mma(0, 1);
-            if (pf) a_next(0);
-            mma(1, 1);
-            if (pf) a_next(1);
-            mma(2, 1);
-            if (pf) a_next(2);
-            mma(3, 1);
-            if (LOCK && do_store) {
-              if (kk < VE / 2) xform_pair(kk, fx, sAn);
-              if (kk == 3) xform_finish(tap - 2, fx, sAn);
-            }
-            if (LOCK) {
-              if (pf) {
-                a_next(3);
-                b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
-              }
-              // one MFMA, then a slice of the other pipes: VALU / transcendental / LDS
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i >= 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                if (i < 4) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-              }
-              __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            } else if (pf) {
-              a_next(3);
-              b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
-              // pin the rotation: 4 MFMA, read, then (MFMA, read) x 4 (the last one 2 reads)
-              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              }
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            // k-pieces stay apart: otherwise the last weight fragment is re-requested INTO the register of the other one,
-            // i.e. only after the next k-piece's first four MFMAs, with its LDS latency exposed
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        };
-        if (!LOCK && do_store) xform_store(tap - 2, cur, sAn);
-        if ((AB & 512) && do_store) xform_store(tap - 2, cur, sAn);   // development: double work per barrier interval
-        // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
-        unsigned long long tq2 = 0;
-        if (AB & 256) { tq2 = __builtin_readcyclecounter(); pc_other += tq2 - tq1; }
-        if (!LOCK) {
+          for (int ni = 0; ni < NI; ++ni) { bH[ni] = ldb(ni, 0); bL[ni] = ldb(ni, 16); }
+          if (do_store) xform_store(tap - 2, cur, sAn);
+          // ---------- phase 2 ("mma") ----------
           if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
           else wait_vmcnt0();
           __syncthreads();  // barrier Y
-        }
-        unsigned long long tq3 = 0;
-        if (AB & 256) { tq3 = __builtin_readcyclecounter(); pc_bary += tq3 - tq2; }
-        __builtin_amdgcn_sched_barrier(0);
-        if (AB & 64) __builtin_amdgcn_s_setprio(1);
-        mma_block();
-        if (AB & 512) {   // development: double work per barrier interval (results are garbage, timing only)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(aptr + ((mi + g) * HW_ + t) * AROW);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
           __builtin_amdgcn_sched_barrier(0);
-          mma_block();
-        }
-        if (AB & 64) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+          for (int sidx = 0; sidx < 2; ++sidx) {
+            const int so = sidx * 64, sn = 64;   // this block's / the next block's byte offset
+            const bool nx = sidx == 0;           // a next block exists inside this K-step
+            // group 1: hi*hi (the lo fragments of A arrive under it)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) aL[mi] = lda(mi, so + 16);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) mm(aH[mi], bH[ni], acc[mi][ni]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 2: hi*lo; bL and aH are dead afterwards -> re-requested for the next block
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) mm(aH[mi], bL[0], acc[mi][0]);
+            if (nx) bL[0] = ldb(0, sn + 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              mm(aH[mi], bL[1], acc[mi][1]);
+              if (nx) aH[mi] = lda(mi, sn);
+            }
+            if (nx) bL[1] = ldb(1, sn + 16);
+            if (nx) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // group 3: lo*hi; bH is dead afterwards
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) mm(aL[mi], bH[0], acc[mi][0]);
+            if (nx) bH[0] = ldb(0, sn);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) mm(aL[mi], bH[1], acc[mi][1]);
+            if (nx) bH[1] = ldb(1, sn);
+            if (nx) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+        // ---- fragments of k-piece 0 ----
+        vec_t a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(ap + mi * HW_ * AROW);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
+        if (do_store) xform_store(tap - 2, cur, sAn);
+        // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
+        if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else wait_vmcnt0();
+        __syncthreads();  // barrier Y
         __builtin_amdgcn_sched_barrier(0);
-        if (AB & 256) pc_mma += __builtin_readcyclecounter() - tq3;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int xo = (kk + 1) << 5;
+          const bool pf = kk < 3;
+          auto mma = [&](int mi, int ni) { MmaT<T>::run(a[mi], b[ni], acc[mi][ni]); };
+          auto a_next = [&](int mi) { a[mi] = *(const vec_t*)(ap + mi * HW_ * AROW + (kk + 1) * 32); };
+          mma(0, 0); mma(1, 0); mma(2, 0); mma(3, 0);
+          if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
+          mma(0, 1);
+          if (pf) a_next(0);
+          mma(1, 1);
+          if (pf) a_next(1);
+          mma(2, 1);
+          if (pf) a_next(2);
+          mma(3, 1);
+          if (pf) {
+            a_next(3);
+            b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
+            // pin the rotation: 4 MFMA, read, then (MFMA, read) x 4 (the last one 2 reads)
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+          // k-pieces stay apart: otherwise the last weight fragment is re-requested INTO the register of the other one,
+          // i.e. only after the next k-piece's first four MFMAs, with its LDS latency exposed
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -460,12 +464,10 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // group 0 reads it.  Halo image c+1 is written in phase 1 of taps 3..8 of chunk c and first read after two more
   // barriers; its previous content was last read three steps before the first write.
   wait_vmcnt0();
-  unsigned long long cyc1 = 0;
-  if (AB & 256) { ts[1] = wall_clock64(); cyc1 = __builtin_readcyclecounter(); }
-  if (!(AB & 1024) && wm == 1) __syncthreads();
+  if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
-  if (!(AB & 1024) && wm == 0) __syncthreads();  // the two wave groups are aligned again
+  if (wm == 0) __syncthreads();  // the two wave groups are aligned again
 
   // ---------------- optional skip phase: acc += x[tile pixels] . Wskip  (the ResBlock's 1x1 skip_connection on its raw
   // input x = cat(sk0, sk1)); a plain 2-stage LDS-DMA pipeline like conv_igemm with taps = 1: A stage = the tile's 256
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) glds16_s(wbase, sb_voff[i], sB0 + stage * B_BYTES + (i * NT + wave * 64) * 16);
     };
-    const int sa_addr0 = (wm * 128 + frow) * 128 + ((fhalf ^ (((wm * 128 + frow) >> 1) & 7)) << 4);
+    const int sa_addr0 = (wm * 128 + frow) * 128 + (((FH * fhalf) ^ (((wm * 128 + frow) >> 1) & 7)) << 4);
     issue_skip(0, 0);
     for (int c = 0; c < sk_chunks; ++c) {
       wait_vmcnt0();
@@ -507,6 +509,32 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       if (c + 1 < sk_chunks) issue_skip((c + 1) & 1, c + 1);
       const int a_off = (c & 1) * 32768 + sa_addr0;
       const int b_off = (c & 1) * B_BYTES + b_addr0;
+      if constexpr (IsSplit<T>::value) {
+        // raw fp32 block input: split into bf16 hi / lo in registers (as conv_igemm's bf16x3 path)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const int so = sidx * 64;
+          bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            split_bf16x8(*(const f32x4*)(sA0 + (a_off ^ so) + mi * 4096), *(const f32x4*)(sA0 + (a_off ^ so ^ 16) + mi * 4096),
+                         ah[mi], al[mi]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = *(const bf16x8*)(sB0 + (b_off ^ so) + ni * 4096);
+            bl[ni] = *(const bf16x8*)(sB0 + (b_off ^ so ^ 16) + ni * 4096);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              f32x16& cc = acc[mi][ni];
+              cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], cc, 0, 0, 0);
+              cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], cc, 0, 0, 0);
+            }
+        }
+      } else {
       vec_t a[MI], b[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA0 + a_off + mi * 4096);
@@ -517,19 +545,18 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         const int xo = (kk + 1) << 5;
         const bool pf = kk < 3;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) Mma2<T>::run(a[mi], b[0], acc[mi][0]);
+        for (int mi = 0; mi < MI; ++mi) MmaT<T>::run(a[mi], b[0], acc[mi][0]);
         if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          Mma2<T>::run(a[mi], b[1], acc[mi][1]);
+          MmaT<T>::run(a[mi], b[1], acc[mi][1]);
           if (pf) a[mi] = *(const vec_t*)(sA0 + (a_off ^ xo) + mi * 4096);
         }
         if (pf) b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 4096);
       }
+      }
     }
   }
-  unsigned long long cyc2 = 0;
-  if (AB & 256) { ts[2] = wall_clock64(); cyc2 = __builtin_readcyclecounter(); }
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   wait_vmcnt0();
@@ -576,7 +603,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       const int row = ps * RPP + lr;
       const size_t m = mbase + row;
       const int n = nbase + lc;
-      if (n < Cout && (!(AB & 4) || p.N < 0)) {
+      if (n < Cout) {
         float v[VE];
 #pragma unroll
         for (int e = 0; e < VE; e += 4) {
@@ -613,7 +640,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
         const vec_t ov = f32_to_vec<T>(v);
         *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
-        if (p.stats && !(AB & 256)) {
+        if (p.stats) {
           float sv[VE];
           vec_to_f32<T>(ov, sv);
 #pragma unroll
@@ -624,7 +651,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
       }
     }
-    if (p.stats && !(AB & 256) && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
+    if (p.stats && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
 #pragma unroll
       for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -644,22 +671,10 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     }
     wave_lds_sync();  // the slab is private to this wave
   }
-  if (AB & 256) {  // development: per-workgroup phase timestamps (100 MHz) + hardware id into the stats buffer
-    ts[3] = wall_clock64();
-    if (tid == 0) {
-      unsigned long long* o = (unsigned long long*)p.stats + (size_t)blockIdx.x * 5;
-      o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3];
-      o[4] = cyc2 - cyc1;   // shader-clock cycles of the main loop (s_memtime): / (ts[2]-ts[1]) * 100 MHz = sustained clock
-    }
-    if (lane == 0 && (wave == 0 || wave == 4)) {   // phase cycle counters of one wave of each ping-pong group
-      unsigned long long* q = (unsigned long long*)p.stats + (size_t)p.ntiles_total * 5 + ((size_t)blockIdx.x * 2 + wm) * 4;
-      q[0] = pc_other; q[1] = pc_mma; q[2] = pc_barx; q[3] = pc_bary;
-    }
-  }
 }
 
-template <typename T, int AB = 0> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T, AB>;
+template <typename T> int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -676,9 +691,9 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
                                     const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
                                     int H, int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1,
                                     int skipC1, const void* skip_weight, void* stream) {
-  const int esz = dtype == IVID_F32 ? 4 : 2;
+  const int esz = ivid_esz(dtype);
+  if (!esz) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
-  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   if (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke) return ivid_set_error("conv3x3_gn: channels must be multiples of the K-step", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("conv3x3_gn: src1 missing", hipSuccess);
   if (W % TW || H % TH) return ivid_set_error("conv3x3_gn: needs W % 32 == 0 and H % 8 == 0 (use ivid_gn_apply + ivid_conv2d otherwise)", hipSuccess);
@@ -704,23 +719,9 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
-#ifdef IVID_DEV_ABLATE
-  if (dtype == IVID_BF16) {
-    static const int ablate = getenv("IVID_FUSED_ABLATE") ? atoi(getenv("IVID_FUSED_ABLATE")) : 0;
-    switch (ablate) {
-      case 1: return launch_fused<__bf16, 1>(a, (hipStream_t)stream);
-      case 2: return launch_fused<__bf16, 2>(a, (hipStream_t)stream);
-      case 4: return launch_fused<__bf16, 4>(a, (hipStream_t)stream);
-      case 8: return launch_fused<__bf16, 8>(a, (hipStream_t)stream);
-      case 64: return launch_fused<__bf16, 64>(a, (hipStream_t)stream);
-      case 256: return launch_fused<__bf16, 256>(a, (hipStream_t)stream);
-      case 512: return launch_fused<__bf16, 512>(a, (hipStream_t)stream);
-      case 1024: return launch_fused<__bf16, 1024>(a, (hipStream_t)stream);
-      default: break;
-    }
-  }
-#endif
   if (dtype == IVID_BF16) return launch_fused<__bf16>(a, (hipStream_t)stream);
+  if (dtype == IVID_F16) return launch_fused<_Float16>(a, (hipStream_t)stream);
+  if (dtype == IVID_BF16X3) return launch_fused<bf16x3_t>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
 }
 

@@ -48,22 +48,6 @@ struct ConvArgs {
   float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
 };
 
-template <typename T> struct Mma;
-template <> struct Mma<__bf16> {
-  // one 16-byte piece per lane = 8 k-values; lanes 0-31 / 32-63 hold consecutive pieces.
-  static __device__ __forceinline__ void run(const bf16x8& a, const bf16x8& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  // one 16-byte piece per lane = 4 k-values; MFMA j pairs k=j of the low-lane piece with k=j
-  // of the high-lane piece.  A and B use the same k permutation, so the sum is unchanged.
-  static __device__ __forceinline__ void run(const f32x4& a, const f32x4& b, f32x16& c) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
-  }
-};
-
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool PF>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const ConvArgs p) {
   typedef typename Elem<T>::vec vec_t;
@@ -238,6 +222,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     const char* sB = sA + A_BYTES;
     // the first fragments are requested BEFORE the next stage's 8 LDS-DMA loads are issued, so their LDS latency
     // hides behind the address arithmetic instead of sitting in front of the first MFMA of the K-step
+    if constexpr (IsSplit<T>::value) {
+      // bf16x3: the K-step is 32 channels.  A stage = fp32 activations (split into bf16 hi/lo in registers, ~20 VALU
+      // ops per fragment against 3 x NI MFMAs of 8 passes each); B stage = host-split weights, pieces 2j / 2j+1 =
+      // hi / lo of channels 8j..8j+7.  MFMA s takes channels 16s + 8*(lane>>5) .. +7 per lane half.
+      auto load_split = [&](int sidx, bf16x8* ah, bf16x8* al, bf16x8* bh, bf16x8* bl) {
+        const int piece = 4 * sidx + 2 * fhalf;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const f32x4 x0 = *(const f32x4*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
+          const f32x4 x1 = *(const f32x4*)(sA + a_off[mi] + (((piece + 1) ^ a_sw[mi]) << 4));
+          split_bf16x8(x0, x1, ah[mi], al[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bh[ni] = *(const bf16x8*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
+          bl[ni] = *(const bf16x8*)(sB + b_off[ni] + (((piece + 1) ^ b_sw[ni]) << 4));
+        }
+      };
+      bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+      load_split(0, ah[0], al[0], bh[0], bl[0]);
+      if (kt + 1 < nk) issue((kt + 1) & 1);
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        if (sidx == 0) load_split(1, ah[1], al[1], bh[1], bl[1]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x16& c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[sidx][mi], bh[sidx][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sidx][mi], bl[sidx][ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sidx][mi], bh[sidx][ni], c, 0, 0, 0);
+          }
+      }
+    } else {
     vec_t a[2][MI], b[2][NI];
     load_frags(sA, sB, 0, a[0], b[0]);
     if (kt + 1 < nk) issue((kt + 1) & 1);
@@ -247,7 +266,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni) MmaT<T>::run(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni]);
+    }
     }
   }
 
@@ -417,9 +437,9 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
                            const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
                            int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
-  const int esz = dtype == IVID_F32 ? 4 : 2;
+  const int esz = ivid_esz(dtype);
+  if (!esz) return ivid_set_error("conv: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
-  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("conv: bad dtype", hipSuccess);
   if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
   if (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke) return ivid_set_error("conv: channels must be multiples of the K-step", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("conv: src1 missing", hipSuccess);
@@ -452,6 +472,8 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
     return pf ? launch_conv<TT, 128, 128, 2, 2, true>(a, s) : launch_conv<TT, 128, 128, 2, 2, false>(a, s);                    \
   } while (0)
   if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);
+  if (dtype == IVID_F16) IVID_CONV_DISPATCH(_Float16);
+  if (dtype == IVID_BF16X3) IVID_CONV_DISPATCH(bf16x3_t);
   IVID_CONV_DISPATCH(float);
 #undef IVID_CONV_DISPATCH
 }

@@ -189,11 +189,15 @@ extern "C" int ivid_silu_f32(const float* x, float* y, long long n, void* stream
 
 extern "C" int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Cpad,
                                  void* out, void* stream) {
-  const int ve = dtype == IVID_F32 ? 4 : 8;
+  if (!ivid_esz(dtype)) return ivid_set_error("nchw_to_nhwc: bad dtype", hipSuccess);
+  const int ve = 16 / ivid_esz(dtype);
   if (Cpad % ve || Cpad < Cin) return ivid_set_error("nchw_to_nhwc: bad Cpad", hipSuccess);
   const int HW = H * W;
   dim3 grid((HW + 255) / 256, N);
-  if (dtype == IVID_F32)
+  if (dtype == IVID_F16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, HW, Cpad,
+                       (char*)out);
+  else if (dtype == IVID_F32 || dtype == IVID_BF16X3)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, HW, Cpad,
                        (char*)out);
   else if (dtype == IVID_BF16)
@@ -206,10 +210,14 @@ extern "C" int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int
 
 extern "C" int ivid_stem_im2col(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
                                 void* stream) {
-  const int ve = dtype == IVID_F32 ? 4 : 8;
+  if (!ivid_esz(dtype)) return ivid_set_error("stem_im2col: bad dtype", hipSuccess);
+  const int ve = 16 / ivid_esz(dtype);
   if (Kpad % ve || Kpad < 9 * Cin || Cin <= 0) return ivid_set_error("stem_im2col: bad Kpad", hipSuccess);
   dim3 grid((H * W + 255) / 256, N);
-  if (dtype == IVID_F32)
+  if (dtype == IVID_F16)
+    hipLaunchKernelGGL(stem_im2col_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
+                       (char*)out);
+  else if (dtype == IVID_F32 || dtype == IVID_BF16X3)
     hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
                        (char*)out);
   else if (dtype == IVID_BF16)

@@ -218,8 +218,8 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
 }
 
 int check_channels(int dtype, int C0, int C1, const void* src1) {
-  const int ve = dtype == IVID_F32 ? 4 : 8;
-  if (dtype != IVID_F32 && dtype != IVID_BF16) return ivid_set_error("gn: bad dtype", hipSuccess);
+  if (!ivid_esz(dtype)) return ivid_set_error("gn: bad dtype", hipSuccess);
+  const int ve = 16 / ivid_esz(dtype);
   if (C0 <= 0 || C0 % ve || C1 < 0 || C1 % ve) return ivid_set_error("gn: channels must be multiples of 16 bytes", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("gn: src1 missing", hipSuccess);
   return 0;
@@ -237,8 +237,11 @@ extern "C" int ivid_gn_partial(int dtype, const void* src0, int C0, const void* 
   if (int e = check_channels(dtype, C0, C1, src1)) return e;
   const int ppc = gn_ppc(HW), nchunks = (HW + ppc - 1) / ppc;
   dim3 grid(nchunks, N);
-  if (dtype == IVID_F32)
+  if (dtype == IVID_F32 || dtype == IVID_BF16X3)
     hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
+                       (const char*)src1, C1, HW, ppc, nchunks, partial);
+  else if (dtype == IVID_F16)
+    hipLaunchKernelGGL(gn_partial_kernel<_Float16>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
                        (const char*)src1, C1, HW, ppc, nchunks, partial);
   else
     hipLaunchKernelGGL(gn_partial_kernel<__bf16>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
@@ -281,8 +284,10 @@ extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* sr
 #define LAUNCH(T, A)                                                                                              \
   hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
                      C1, ab, (char*)out, H, W, resample, ppc)
-  if (dtype == IVID_F32) {
+  if (dtype == IVID_F32 || dtype == IVID_BF16X3) {
     if (act) LAUNCH(float, 1); else LAUNCH(float, 0);
+  } else if (dtype == IVID_F16) {
+    if (act) LAUNCH(_Float16, 1); else LAUNCH(_Float16, 0);
   } else {
     if (act) LAUNCH(__bf16, 1); else LAUNCH(__bf16, 0);
   }

@@ -9,10 +9,14 @@ with strict=True on reference checkpoints.
 
 The module holds fp32 master parameters only as a checkpoint container; compute happens in the
 HIP launch plan (plan.py) on weights repacked once per precision:
-    precision "fp32": exact-fp32 MFMA (parity mode, bit-comparable to an fmaf chain)
-    precision "bf16": bf16 MFMA with fp32 accumulate, fp32 GroupNorm/softmax/embeddings (perf mode)
-`use_fp16=True` configs (the reference's fp16 torso) select "bf16"; override with the extra kwarg
-`precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
+    precision "fp32"  : exact-fp32 MFMA (parity mode, bit-comparable to an fmaf chain, ~1e-6 vs the reference)
+    precision "bf16x3": fp32 storage, MFMA operands split into bf16 hi+lo, 3 bf16 MFMAs per product (<= 1e-3 parity
+                        at a third of the bf16 MFMA rate instead of the fp32 MFMA's sixteenth)
+    precision "fp16"  : fp16 storage + fp16 MFMA, fp32 accumulate, fp32 GroupNorm/softmax/embeddings -- the
+                        reference's own `use_fp16` torso (adm.py:508-514, backbones/utils.py:6-13)
+    precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
+`use_fp16=True` configs select "fp16" like the reference; override with the extra kwarg `precision=` or the
+environment variable IVID_PRECISION.  There is no CPU path: calling forward
 without a GPU / without the built library raises.
 """
 import math
@@ -70,7 +74,7 @@ class AdmUnet2d(nn.Module):
                                use_scale_shift_norm, resblock_updown)
         precision = os.environ.get("IVID_PRECISION", precision)
         if precision is None:
-            precision = "bf16" if use_fp16 else "fp32"
+            precision = "fp16" if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
         self.tile_cfg = int(os.environ.get("IVID_TILE_CFG", "0"))
@@ -109,15 +113,15 @@ class AdmUnet2d(nn.Module):
 
     # ---- precision / packing ----
     def set_precision(self, precision):
-        if precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
         self._packed = None
         self._plans = {}
 
     def convert_to_fp16(self):
-        """Reference API (adm.py:508-514): low-precision torso -> bf16 MFMA perf mode here."""
-        self.set_precision("bf16")
+        """Reference API (adm.py:508-514): fp16 torso (fp16 MFMA operands, fp32 accumulate / GroupNorm / softmax)."""
+        self.set_precision("fp16")
 
     def convert_to_fp32(self):
         self.set_precision("fp32")
@@ -156,7 +160,7 @@ class AdmUnet2d(nn.Module):
                     "AdmUnet2d runs only on an MI355X (HIP) device: move it with .cuda() first; "
                     "ivid_amd has no CPU execution path")
             _lib.load()
-            dt = _lib.F32 if self.precision == "fp32" else _lib.BF16
+            dt = _lib.PRECISIONS[self.precision]
             self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt)
         return self._packed
 

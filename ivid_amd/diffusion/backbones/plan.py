@@ -19,7 +19,17 @@ import torch
 from ... import _lib
 from .spec import Attn, Res, UNetSpec
 
-_TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+_TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.BF16X3: torch.float32}
+
+
+def split_pack(w2d):
+    """IVID_BF16X3 weight layout: fp32 [Cout, K] -> bf16 [Cout, 2K]; per 8 input channels 8 x hi then 8 x lo
+    (hi = bf16(w) round-to-nearest-even, lo = bf16(w - hi)), so a row keeps the byte size of an fp32 row."""
+    cout, k = w2d.shape
+    assert k % 8 == 0
+    hi = w2d.to(torch.bfloat16)
+    lo = (w2d - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.view(cout, k // 8, 8), lo.view(cout, k // 8, 8)], dim=2).reshape(cout, 2 * k).contiguous()
 
 
 def _pad_to(c, m):
@@ -33,20 +43,22 @@ class PackedWeights:
     def __init__(self, spec: UNetSpec, sd, device, dtype):
         self.dtype = dtype
         tdt = _TORCH_DT[dtype]
-        self.kstep = 32 if dtype == _lib.F32 else 64
+        self.kstep = 128 // _lib.esz(dtype)
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
         t = {}
+        # matrix operand of the MFMA kernels: compute dtype, or the hi/lo split form of the bf16x3 mode
+        mat = (lambda w: split_pack(w.contiguous())) if dtype == _lib.BF16X3 else (lambda w: w.to(tdt).contiguous())
 
         def conv3(name, pad_cin=None):
             w = g(name + ".weight").permute(0, 2, 3, 1)  # [Cout,3,3,Cin]
             if pad_cin is not None and pad_cin != w.shape[-1]:
                 w = torch.nn.functional.pad(w, (0, pad_cin - w.shape[-1]))
-            t[name + ".weight"] = w.reshape(w.shape[0], -1).to(tdt).contiguous()
+            t[name + ".weight"] = mat(w.reshape(w.shape[0], -1))
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
         def conv1(name):
             w = g(name + ".weight")
-            t[name + ".weight"] = w.reshape(w.shape[0], -1).to(tdt).contiguous()
+            t[name + ".weight"] = mat(w.reshape(w.shape[0], -1))
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
         def vec(name):
@@ -56,7 +68,7 @@ class PackedWeights:
         # stem: the 3x3 patch of the few input channels is ONE K row (k = tap*Cin + c, ivid_stem_im2col), padded to a K-step
         self.stem_k = _pad_to(9 * spec.in_channels, self.kstep)
         ws = g("input_blocks.0.0.weight").permute(0, 2, 3, 1).reshape(spec.stem_out, -1)   # [Cout, 9*Cin]
-        t["input_blocks.0.0.weight"] = torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])).to(tdt).contiguous()
+        t["input_blocks.0.0.weight"] = mat(torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])))
         t["input_blocks.0.0.bias"] = g("input_blocks.0.0.bias").contiguous()
         emb_w, emb_b = [], []
         for op in [o for st in spec.stages for o in st.ops]:
@@ -70,6 +82,8 @@ class PackedWeights:
             else:
                 vec(p + ".norm"); conv1(p + ".qkv"); conv1(p + ".proj_out")
         vec("out.0"); conv3("out.2")
+        if dtype == _lib.BF16X3:   # the output head runs its fp32 kernel in this mode (0.05 % of the FLOPs): plain fp32 weights
+            t["out.2.weight"] = g("out.2.weight").permute(0, 2, 3, 1).reshape(spec.out_channels, -1).contiguous()
         # embedding path stays fp32 in both modes (the reference never casts nn.Linear, backbones/utils.py:6-13)
         t["emb_all.weight"] = torch.cat(emb_w, 0).contiguous()
         t["emb_all.bias"] = torch.cat(emb_b, 0).contiguous()
@@ -136,7 +150,7 @@ class UNetPlan:
         self._sum_bias = {}
         self.taps = {}
         self.dtype = weights.dtype
-        self.esz = 4 if self.dtype == _lib.F32 else 2
+        self.esz = _lib.esz(self.dtype)
         self.bsrc = bsrc
         self.n = 2 * bsrc if stacked else bsrc
         self.null_from = bsrc if stacked else self.n
@@ -390,8 +404,8 @@ class UNetPlan:
         else:
             act = self._gn(h, None, "out.0", None, 0, 1)
             self._free(h)
-            self._conv(self.dtype, act.ptr, sp.final_c, None, 0, "out.2", self.out.data_ptr(), None, 0, 1, n, S, S,
-                       sp.out_channels, 9)
+            self._conv(_lib.F32 if self.dtype == _lib.BF16X3 else self.dtype, act.ptr, sp.final_c, None, 0, "out.2",
+                       self.out.data_ptr(), None, 0, 1, n, S, S, sp.out_channels, 9)
             self._free(act)
 
     # ---- execution ----

@@ -80,10 +80,16 @@ def build_spec(image_size, in_channels, model_channels, out_channels, num_res_bl
 
     def heads_for(c):
         if num_head_channels == -1:
-            return num_heads
-        if c % num_head_channels:
-            raise ValueError(f"q,k,v channels {c} is not divisible by num_head_channels {num_head_channels}")
-        return c // num_head_channels
+            h = num_heads
+        else:
+            if c % num_head_channels:
+                raise ValueError(f"q,k,v channels {c} is not divisible by num_head_channels {num_head_channels}")
+            h = c // num_head_channels
+        # csrc/attn.hip is written for head dim 64 (every ivid config: num_head_channels = 64); anything else would
+        # stride the legacy [head][q|k|v][d] interleave wrongly, so refuse it here instead of returning garbage
+        if not h or c % h or c // h != 64:
+            raise NotImplementedError(f"attention head dim {c}/{h}: the HIP attention kernel supports head dim 64 only")
+        return h
 
     stages: List[Stage] = []
     emb_off = 0
@@ -107,6 +113,8 @@ def build_spec(image_size, in_channels, model_channels, out_channels, num_res_bl
             ops = [res(f"input_blocks.{idx}.0", ch, cout, side)]
             ch = cout
             if side in att:
+                if (side * side) % 64:
+                    raise NotImplementedError(f"attention at {side}x{side}: the HIP kernel needs T % 64 == 0")
                 ops.append(Attn(f"input_blocks.{idx}.1", ch, side, heads_for(ch)))
             stages.append(Stage("in", ops))
             skip_chs.append(ch)

@@ -62,8 +62,13 @@ class GaussianDiffusion:
 
 def cfg_branches(backbone, x, t, classes, strength):
     """(eps_cond, eps_uncond, strength) with one stacked forward when the backbone supports it."""
-    if classes is None or not strength > 0:
-        return backbone(x, t, classes), None, 0.0
+    if classes is None:
+        return backbone(x, t, None), None, 0.0
+    if not strength > 0:
+        # classifier_free_guidance.py:39-42: (1 + s) * eps_c - (s * eps_u if s > 0 else 0): no second forward, but the
+        # conditional branch is still scaled by (1 + s) for negative strengths
+        ec = backbone(x, t, classes)
+        return (ec if strength == 0 else (1 + strength) * ec), None, 0.0
     if hasattr(backbone, "forward_cfg"):
         ec, eu = backbone.forward_cfg(x, t, classes)
         return ec, eu, float(strength)

@@ -162,7 +162,7 @@ def main(argv=None):
     p.add_argument("--atol", type=float, default=0.03)
     p.add_argument("--rtol", type=float, default=0.03)
     p.add_argument("--erode_rgb", type=int, default=3)
-    p.add_argument("--precision", type=str, default=None, help="fp32 (parity) | bf16 (perf); default: from config use_fp16")
+    p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 (parity at MFMA speed) | fp16 | bf16; default: fp16 if the config says use_fp16 else fp32")
     # 128 -> 256 super-resolution of every generated view (BASELINE config 5).  Not in the reference CLI: the reference ships
     # the SR model and SuperResCFG but no inference driver for them (only SuperResTrainer.sample, trainers/superres.py:97-134)
     p.add_argument("--config_sr", type=str, default=None, help="e.g. configs/rgbd_imagenet_adm_256_128_small_sr.json")
@@ -238,5 +238,16 @@ def main(argv=None):
         t.join()
 
 
+def cli(argv=None):
+    """Entry point: one process per GPU like the reference's mp.spawn (sample.py:340-348) unless a launcher already
+    made this process a rank."""
+    import sys
+    argv = sys.argv[1:] if argv is None else list(argv)
+    rc = parallel.spawn_one_process_per_gpu("ivid_amd.inference.sample", argv, module=True)
+    if rc is not None:
+        raise SystemExit(rc)
+    main(argv)
+
+
 if __name__ == "__main__":
-    main()
+    cli()

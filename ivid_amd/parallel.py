@@ -34,6 +34,32 @@ def init_from_env(backend=None):
     return rank_world()
 
 
+def spawn_one_process_per_gpu(script, argv, nproc=None, module=False):
+    """The reference's `mp.spawn(main, nprocs=torch.cuda.device_count())` (inference/sample.py:340-348): when this
+    process was NOT started by a launcher (no WORLD_SIZE) and the node has more than one GPU, re-exec `script argv`
+    under torch.distributed.run with one rank per GPU and return its exit code; otherwise return None and the caller
+    carries on as the single rank (or as the rank torchrun made it)."""
+    import socket
+    import subprocess
+    import sys
+    if "WORLD_SIZE" in os.environ:
+        return None
+    if nproc is None:
+        nproc = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    if nproc <= 1:
+        return None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + (["-m"] if module else []) + [script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def shard(seq, rank=None, world=None):
     """Rank-strided shard, exactly `seq[rank::world_size]` (sample.py:199-202); None passes through."""
     if seq is None:
@@ -66,10 +92,25 @@ def broadcast_state_dict(schema, state_dict=None, device=None, src=0):
             n *= s
         sizes.append(n)
     total = sum(sizes)
+    # strict=True semantics on the source rank (missing / unexpected keys, per-tensor shapes), and the verdict is
+    # exchanged BEFORE the payload so that a bad checkpoint raises on every rank instead of leaving the others hung
+    # in the broadcast
+    err = ""
     if rank == src:
+        names = {n for n, _ in schema}
         missing = [n for n, _ in schema if n not in state_dict]
-        if missing:
-            raise KeyError(f"checkpoint lacks {missing[:3]}...")
+        unexpected = [k for k in state_dict if k not in names]
+        bad = [n for n, shape in schema if n in state_dict and tuple(state_dict[n].shape) != tuple(shape)]
+        if missing or unexpected or bad:
+            err = f"checkpoint does not match the config: missing {missing[:3]}, unexpected {unexpected[:3]}, wrong shape {bad[:3]}"
+    if world > 1:
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+        dist.broadcast(flag, src=src)
+        if int(flag.item()) and not err:
+            err = f"rank {src} rejected the checkpoint (see its error)"
+    if err:
+        raise KeyError(err)
+    if rank == src:
         flat = torch.cat([state_dict[n].detach().reshape(-1).to(torch.float32) for n, _ in schema]).to(device)
         assert flat.numel() == total
     else:

@@ -16,7 +16,7 @@ import gpu_util as G
 from oracle import adm_oracle, sampler_oracle
 
 pytestmark = pytest.mark.gpu
-DTYPES = [0, 1]  # IVID_F32, IVID_BF16
+DTYPES = [0, 1, 2, 3]  # IVID_F32, IVID_BF16, IVID_F16, IVID_BF16X3
 
 
 def conv_ref(x0, x1, w, b, res, res_mode, dtype):
@@ -40,7 +40,7 @@ def run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg):
     taps = k * k
     d0 = G.to_nhwc(x0, dtype)
     d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
     bd = b.cuda() if b is not None else None
     rd = G.to_nhwc(res, dtype) if res is not None else None
     if out_mode == 0:
@@ -85,7 +85,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv2d(case, dtype):
     name, N, H, W, C0, C1, Cout, k, res_mode, out_mode, tile_cfg = case
-    if dtype == 0 and (C0 % 32 or C1 % 32):
+    if dtype in (0, 3) and (C0 % 32 or C1 % 32):
         pytest.skip("K-step")
     s = sum(map(ord, name)) % 1000
     x0 = common.seeded_randn(s, N, C0, H, W)
@@ -102,7 +102,7 @@ def test_conv2d(case, dtype):
     got = run_conv(dtype, x0, x1, w, b, res, res_mode, out_mode, tile_cfg)
     ref = conv_ref(x0, x1, w, b, res, res_mode, dtype)
     e = common.rel_l2(got, ref)
-    G.report(f"conv/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    G.report(f"conv/{name}/{G.DN[dtype]}", rel_l2=e, max_rel=common.max_rel(got, ref))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype), f"{name}: rel_l2 {e}"
 
@@ -157,7 +157,7 @@ def test_conv3x3_gn_fused(case, dtype):
     d0 = G.to_nhwc(x0, dtype)
     d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
     ab = torch.stack([a, b], -1).contiguous().cuda()
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
     bd = bias.cuda()
     rd = G.to_nhwc(res, dtype) if res is not None else None
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
@@ -167,7 +167,7 @@ def test_conv3x3_gn_fused(case, dtype):
     torch.cuda.synchronize()
     got = G.from_nhwc(out)
     e = common.rel_l2(got, ref)
-    G.report(f"conv3x3_gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    G.report(f"conv3x3_gn/{name}/{G.DN[dtype]}", rel_l2=e, max_rel=common.max_rel(got, ref))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
     # one block = 4 image rows x 32 columns; blocks ordered (image, 4-row band, 32-column strip)
@@ -207,8 +207,8 @@ def test_conv3x3_gn_fused_with_skip_conv(case, dtype):
     d0 = G.to_nhwc(x0, dtype)
     d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
     ab = torch.stack([a, b], -1).contiguous().cuda()
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
-    wsp = wsk.reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    wsp = G.pack_w(wsk.reshape(Cout, -1), dtype)
     bd = bias.cuda()
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
     stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
@@ -217,7 +217,7 @@ def test_conv3x3_gn_fused_with_skip_conv(case, dtype):
     torch.cuda.synchronize()
     got = G.from_nhwc(out)
     e = common.rel_l2(got, ref)
-    G.report(f"conv3x3_gn_skip/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    G.report(f"conv3x3_gn_skip/{name}/{G.DN[dtype]}", rel_l2=e, max_rel=common.max_rel(got, ref))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
     o = out.float().reshape(N, H // 4, 4, W // 32, 32, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 128, Cout)
@@ -235,7 +235,7 @@ def test_stem_im2col_then_1x1_equals_the_3x3_stem_conv(cin, dtype):
     x = common.seeded_randn(10 + cin, Bsrc, cin, H, W)
     w = common.seeded_randn(20 + cin, Cout, cin, 3, 3) / np.sqrt(9 * cin)
     b = common.seeded_randn(30 + cin, Cout) * 0.1
-    kstep = 32 if dtype == 0 else 64
+    kstep = 32 if dtype in (0, 3) else 64
     kpad = (9 * cin + kstep - 1) // kstep * kstep
     cols = torch.full((N, H, W, kpad), float("nan"), device="cuda", dtype=G.tdt(dtype))
     xd = x.cuda()
@@ -251,13 +251,13 @@ def test_stem_im2col_then_1x1_equals_the_3x3_stem_conv(cin, dtype):
     wp = torch.zeros(Cout, kpad)
     wp[:, :9 * cin] = w.permute(0, 2, 3, 1).reshape(Cout, -1)
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
-    wd, bd = wp.to("cuda", G.tdt(dtype)), b.cuda()
+    wd, bd = G.pack_w(wp, dtype), b.cuda()
     L.call("ivid_conv2d", dtype, L.ptr(cols), kpad, None, 0, L.ptr(wd), L.ptr(bd), L.ptr(out), None, 0,
            0, N, H, W, Cout, 1, 0, None, G.stream())
     torch.cuda.synchronize()
     ref = F.conv2d(G.rounded(x, dtype).double(), G.rounded(w, dtype).double(), b.double(), padding=1).float().repeat(2, 1, 1, 1)
     e = common.rel_l2(G.from_nhwc(out), ref)
-    G.report(f"stem_im2col/cin{cin}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e)
+    G.report(f"stem_im2col/cin{cin}/{G.DN[dtype]}", rel_l2=e)
     assert e < G.tol(dtype, 2e-6, 4e-3), e
 
 
@@ -267,7 +267,7 @@ def test_stem_im2col_then_1x1_equals_the_3x3_stem_conv(cin, dtype):
 def test_conv3x3_gn_out_head(case, dtype):
     """The UNet head (adm.py:483-487, 565-566): GN-apply + SiLU + conv3x3 to a few channels, fp32 NCHW out, one kernel."""
     name, N, H, W, Cc, Cout = case
-    if dtype == 0 and Cc % 32:
+    if dtype in (0, 3) and Cc % 32:
         pytest.skip("K-step")
     L = G.lib()
     s_ = sum(map(ord, name)) % 1000
@@ -280,14 +280,14 @@ def test_conv3x3_gn_out_head(case, dtype):
     ref = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1).float()
     dx = G.to_nhwc(x, dtype)
     ab = torch.stack([a, b], -1).contiguous().cuda()
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", G.tdt(dtype))
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), 0 if dtype == 3 else dtype)   # bf16x3: plain fp32 weights here
     bd = bias.cuda()
     out = torch.full((N, Cout, H, W), float("nan"), device="cuda", dtype=torch.float32)
     L.call("ivid_conv3x3_gn_out", dtype, L.ptr(dx), Cc, L.ptr(ab), L.ptr(wp), L.ptr(bd), L.ptr(out), N, H, W, Cout, G.stream())
     torch.cuda.synchronize()
     got = out.cpu()
     e = common.rel_l2(got, ref)
-    G.report(f"conv3x3_gn_out/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e)
+    G.report(f"conv3x3_gn_out/{name}/{G.DN[dtype]}", rel_l2=e)
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 2e-5, 6e-3), f"{name}: rel_l2 {e}"
 
@@ -396,7 +396,7 @@ def test_groupnorm_film_silu_resample(case, dtype):
     torch.cuda.synchronize()
     got = G.from_nhwc(out)
     e = common.rel_l2(got, y)
-    G.report(f"gn/{name}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, y))
+    G.report(f"gn/{name}/{G.DN[dtype]}", rel_l2=e, max_rel=common.max_rel(got, y))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 1e-5, 5e-3), f"{name}: rel_l2 {e}"
 
@@ -442,7 +442,7 @@ def test_attention(T, heads, N, dtype):
     torch.cuda.synchronize()
     got = out.float().permute(0, 2, 1).cpu()
     e = common.rel_l2(got, ref)
-    G.report(f"attn/T{T}_h{heads}/{'f32' if dtype == 0 else 'bf16'}", rel_l2=e, max_rel=common.max_rel(got, ref))
+    G.report(f"attn/T{T}_h{heads}/{G.DN[dtype]}", rel_l2=e, max_rel=common.max_rel(got, ref))
     assert torch.isfinite(got).all()
     assert e < G.tol(dtype, 2e-5, 1.5e-2), f"T={T}: rel_l2 {e}"
 

@@ -63,3 +63,39 @@ def test_single_process_paths():
     sd = C.synth_weights(C.MINI_UNCLASS, 3)
     out = parallel.broadcast_state_dict(C.schema_for(C.MINI_UNCLASS), sd, device=torch.device("cpu"))
     assert all(torch.equal(out[k], sd[k]) for k in sd)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun must come up as TWO ranks that see each other through a collective
+    (here gloo on CPU; on the GPU box the same path runs over RCCL) and must refuse a mismatching WORLD_SIZE."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(C.ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--launcher-dry-run"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["self_launched"] is True
+    assert [p[0] for p in out["ranks_seen"]] == [0, 1]
+    # an external launcher with the wrong world size is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--launcher-dry-run"], env=env2, capture_output=True, text=True,
+                        timeout=600)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+def test_spawn_helper_is_a_no_op_under_a_launcher_or_on_one_device():
+    from ivid_amd import parallel
+    assert parallel.spawn_one_process_per_gpu("x.py", [], nproc=1) is None
+    old = os.environ.get("WORLD_SIZE")
+    os.environ["WORLD_SIZE"] = "4"
+    try:
+        assert parallel.spawn_one_process_per_gpu("x.py", [], nproc=8) is None
+    finally:
+        if old is None:
+            del os.environ["WORLD_SIZE"]
+        else:
+            os.environ["WORLD_SIZE"] = old
