@@ -189,8 +189,12 @@ int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const f
  *   rgbd          : fp32 [B,4,S,S]; input_mode 0: network output in [-1,1] (RGB + z-buffer depth encoded with nearv/farv,
  *                   inference/sample.py:83,126); input_mode 1: a stored scene — RGB in [0,1] and METRIC depth
  *                   (load_scene, inference/utils.py:103-113)
- *   padding       : < 0: padding='frustum' (the sampling driver, sample.py:129-133); >= 0: numeric padding in pixels
- *                   (load_scene uses 32, utils.py:201-205)
+ *   padding       : -1: padding='frustum' (the sampling driver, sample.py:129-133); >= 0: numeric padding in pixels
+ *                   (load_scene uses 32, forward_backward_warp the image size; utils.py:201-205); -2: padding=None
+ *                   (forward_backward_warp's second mesh, utils.py:391-398): the ring of the (S+2)^2 grid then holds copies
+ *                   of the border vertices -- degenerate triangles that are never rasterised -- and no padding flag
+ *   atol, rtol    : discontinuity test (diff > atol AND inverse-diff > rtol); +inf/+inf = the reference's atol=rtol=None
+ *                   (no flagging at all, utils.py:223)
  *   inv_modelview : fp32 [B][16] row-major camera->world matrix (glm.inverse(modelview), utils.py:232-237)
  *   verts         : out fp32 [B][(S+2)^2][9] = world position(3), world normal(3), uv(2), flag(1) with
  *                   flag = 1*discontinuity + 2*padding + 4*eroded (utils.py:249) — the reference's VBO layout
@@ -213,11 +217,14 @@ int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview,
  *             mask_color / mask_depth u8 [B][R][R]
  *   work / work_cap   : caller-owned queue of the LARGE triangles (skirt / discontinuity sheets seen from another
  *                       camera): int32 [2 + 2*work_cap]; they are rasterised by one workgroup each in a second pass
- *                       instead of by their own thread.  work_cap = 0 disables the second pass (slow, same result). */
+ *                       instead of by their own thread.  work_cap = 0 disables the second pass (slow, same result).
+ *   color_f32         : NULL, or fp32 [B][R][R][3]: the colour BEFORE to8b, i.e. `color` of the edict that
+ *                       AggregationRenderer.render returns (moderngl_renderer.py:317-319,333-338)
+ * Pixel centres exactly on a triangle edge follow the top-left fill rule. */
 int ivid_warp_render(const float* verts, const unsigned char* diag, const float* colors, const float* campos, int NV,
                      int B, int S, const float* mvp, int R, float rnear, float rfar, unsigned long long* zbuf,
                      unsigned char* color8, float* depth_lin, unsigned char* mask_color, unsigned char* mask_depth,
-                     int* work, int work_cap, void* stream);
+                     int* work, int work_cap, float* color_f32, void* stream);
 /* Step 3: aggregate_conditions' SSAA resolve (rgbd_3d/utils.py:450-467): Pillow-exact 8-bit LANCZOS R->S
  * (two integer passes; bounds int32 [S][2], coeffs int32 [S][ksize] with 22 fractional bits computed by the host),
  * centre-sample depth + project_depth (:61-67), masks > 75 % of the ssaa^2 sub-pixels, depth_edge (:311-332),
@@ -230,6 +237,21 @@ int ivid_warp_resolve(const unsigned char* color8, const float* depth_lin, const
                       int ksize, const float* lut255, float nearv, float farv, float atol, float rtol, int erode,
                       unsigned char* tmp_h, unsigned char* tmp_small, float* tmp_dproj, unsigned char* tmp_masks,
                       float* color, float* depth, float* mask, float* mask_rgb, float* convex, void* stream);
+
+/* ---- SimpleRenderer.render (moderngl_renderer.py:96-148; shaders/simple.vsh, simple.fsh): the training-time warp renderer
+ *      of forward_backward_warp (rgbd_3d/utils.py:335-417, datasets/base.py:219,238) on the same z-buffer kernels: ONE mesh
+ *      per sample (verts/diag/colors [B][...] as ivid_mesh_build writes them), one depth-tested draw, no discard.
+ *   outputs: color_f32 fp32 [B][R][R][3] (NEAREST texel of front faces, else 0), depth_lin fp32 [B][R][R] (linearised
+ *            window depth; `rfar` where nothing was drawn), mask u8 [B][R][R] (alpha > 0.5: front face and not a
+ *            discontinuity edge).  zbuf: scratch u64 [B][R*R]; work as in ivid_warp_render. */
+int ivid_simple_render(const float* verts, const unsigned char* diag, const float* colors, int B, int S, const float* mvp,
+                       int R, float rnear, float rfar, unsigned long long* zbuf, int* work, int work_cap, float* color_f32,
+                       float* depth_lin, unsigned char* mask, void* stream);
+/* to8b + Pillow's 8-bit LANCZOS R -> S (`np.array(Image.fromarray(to8b(res.color)).resize(..., LANCZOS))`, utils.py:387,
+ * 401,454) of a float colour buffer [B][R][R][3]: out8 u8 [B][S][S][3]; tmp_hi8 u8 [B][R][R][3], tmp_h u8 [B][R][S][3];
+ * bounds/coeffs/ksize = Pillow's coefficient tables (ivid_amd/rgbd_3d/resample.py). */
+int ivid_resample8_lanczos(const float* color_f32, int B, int R, int S, const int* bounds, const int* coeffs, int ksize,
+                           unsigned char* tmp_hi8, unsigned char* tmp_h, unsigned char* out8, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,9 @@ SIGNATURES = {
     "ivid_mesh_build": (i32, [vp, i32, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float,
                               i32, vp, vp, vp, vp, vp, vp]),
     "ivid_warp_render": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32,
-                               vp]),
+                               vp, vp]),
+    "ivid_simple_render": (i32, [vp, vp, vp, i32, i32, vp, i32, C.c_float, C.c_float, vp, vp, i32, vp, vp, vp, vp]),
+    "ivid_resample8_lanczos": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
     "ivid_warp_resolve": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, C.c_float, C.c_float, C.c_float,
                                 C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
 }

@@ -559,15 +559,44 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   }
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
-  wait_vmcnt0();
-  __syncthreads();
   constexpr int LDC = WTN + 4;
-  float* slab = (float*)smem + wave * (32 * LDC);
+  constexpr int LPR = WTN / VE, RPP = 64 / LPR, NPS = 32 / RPP;   // lanes per slab row, rows per pass, passes per fragment
   const int Cout = p.Cout;
+  const int nbase = n0 + wn * WTN;
+  const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+  // Residual (same size / nearest-x2 of a half-size tensor): ALL loads of the wave's four fragments are issued here, in
+  // one batch, before the accumulators start moving -- one HBM latency for the whole epilogue instead of one per
+  // fragment (the per-fragment form exposed it four times: a same-size residual cost ~20 % on the 128^2 256->256 layers).
+  // The fragment registers of the main loop are dead by now, so the 8 pieces fit.
+  // (fp32 storage: 8 pieces per lane and fragment -- batching four fragments would spill, so those modes prefetch per fragment)
+  constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
+  vec_t rres[HB][NPS];
+  auto load_res = [&](int mi) {
+    const int y = y0 + wm * 4 + mi;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int xr = x0 + ps * RPP + lr;
+      const size_t pix = p.res_mode == 1 ? ((size_t)img * p.H + y) * p.W + xr
+                                         : ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (xr >> 1);
+      rres[mi % HB][ps] = *(const vec_t*)(p.res + (pix * Cout + nbase + lc) * sizeof(T));
+    }
+  };
+  const bool res12 = (p.res_mode == 1 || p.res_mode == 2) && nbase + lc < Cout;
+  if (HB == MI && res12) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) load_res(mi);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads of the last K-step done (DMA is waited below)
+  {
+    // every LDS-DMA of the main loop / skip phase has landed long ago (the last stage was consumed); only the residual
+    // loads may be in flight, and they must stay in flight across this barrier
+    __builtin_amdgcn_s_barrier();
+  }
+  float* slab = (float*)smem + wave * (32 * LDC);
   float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's 128 pixels (fused gn_partial)
   float bv[VE];              // this lane's bias values: the same 16-byte channel piece in every pass
   {
-    const int nb = n0 + wn * WTN + (lane % (WTN / VE)) * VE;
+    const int nb = nbase + lc;
 #pragma unroll
     for (int e = 0; e < VE; ++e) bv[e] = (p.bias && nb < Cout) ? p.bias[nb + e] : 0.f;
   }
@@ -575,17 +604,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   for (int mi = 0; mi < MI; ++mi) {
     const int y = y0 + wm * 4 + mi;                        // this fragment = image row y, pixels x0 .. x0+31
     const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;
-    const int nbase = n0 + wn * WTN;
-    constexpr int LPR = WTN / VE, RPP = 64 / LPR;
-    const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-    // same-size residual: all of the fragment's loads are issued BEFORE the transpose, so their latency hides behind
-    // the slab traffic instead of sitting in front of every store
-    vec_t rres[32 / RPP];
-    if (p.res_mode == 1 && nbase + lc < Cout) {
-#pragma unroll
-      for (int ps = 0; ps < 32 / RPP; ++ps)
-        rres[ps] = *(const vec_t*)(p.res + ((mbase + ps * RPP + lr) * Cout + nbase + lc) * sizeof(T));
-    }
+    if (HB == 1 && res12) load_res(mi);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -612,15 +631,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < VE; ++e) v[e] += bv[e];
-        if (p.res_mode == 1) {
+        if (p.res_mode == 1 || p.res_mode == 2) {
           float rv[VE];
-          vec_to_f32<T>(rres[ps], rv);
-#pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] += rv[e];
-        } else if (p.res_mode == 2) {
-          const size_t pix = ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + ((x0 + row) >> 1);
-          float rv[VE];
-          vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
+          vec_to_f32<T>(rres[mi % HB][ps], rv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += rv[e];
         } else if (p.res_mode == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)

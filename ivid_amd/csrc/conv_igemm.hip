@@ -284,23 +284,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
 #pragma unroll
     for (int e = 0; e < VE; ++e) bv[e] = (p.bias && nb < Cout) ? p.bias[nb + e] : 0.f;
   }
+  constexpr int LPR = WTN / VE;   // lanes per slab row
+  constexpr int RPP = 64 / LPR;   // rows per pass
+  constexpr int NPS = 32 / RPP;   // passes per fragment
+  const int nbase = n0 + wn * WTN;
+  const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
+  // same-size residual: the loads of ALL fragments of the wave are issued up front, in one batch -- one memory latency
+  // for the whole epilogue instead of one per fragment; their latency hides behind the first transpose
+  // (fp32 storage: a fragment's residual is 8 pieces per lane -- batching all fragments would spill, so those modes keep
+  // the per-fragment prefetch)
+  constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
+  vec_t rres[HB][NPS];
+  auto load_res = [&](int mi) {
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int m = m0 + wm * WTM + mi * 32 + ps * RPP + lr, n = nbase + lc;
+      if (m < p.M && n < Cout) rres[mi % HB][ps] = *(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T));
+    }
+  };
+  if (HB == MI && p.out_mode == 0 && p.res_mode == 1) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) load_res(mi);
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int mbase = m0 + wm * WTM + mi * 32;
-    const int nbase = n0 + wn * WTN;
-    constexpr int LPR = WTN / VE;   // lanes per slab row
-    constexpr int RPP = 64 / LPR;   // rows per pass
-    const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-    // same-size residual: all of the fragment's loads are issued BEFORE the transpose, so their latency hides behind
-    // the slab traffic instead of sitting in front of every store
-    vec_t rres[32 / RPP];
-    if (p.out_mode == 0 && p.res_mode == 1) {
-#pragma unroll
-      for (int ps = 0; ps < 32 / RPP; ++ps) {
-        const int m = mbase + ps * RPP + lr, n = nbase + lc;
-        if (m < p.M && n < Cout) rres[ps] = *(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T));
-      }
-    }
+    if (HB == 1 && p.out_mode == 0 && p.res_mode == 1) load_res(mi);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           for (int e = 0; e < VE; ++e) v[e] += bv[e];
           if (p.res_mode == 1) {
             float rv[VE];
-            vec_to_f32<T>(rres[ps], rv);
+            vec_to_f32<T>(rres[mi % HB][ps], rv);
 #pragma unroll
             for (int e = 0; e < VE; ++e) v[e] += rv[e];
           } else if (p.res_mode != 0) {

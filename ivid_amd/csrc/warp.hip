@@ -33,6 +33,8 @@ struct MeshParams {
   float atol, rtol;
   int erode;
   int frustum;              // 1: padding='frustum' (sample.py), 0: numeric padding of `padpx` pixels (load_scene, render.py)
+  int nopad;                // 1: padding=None (forward_backward_warp's second mesh): the ring of the padded grid holds COPIES
+                            //    of the border vertices (degenerate triangles, never rasterised) and carries no padding flag
   double padpx;
   int metric;               // 1: input holds RGB in [0,1] and METRIC depth (a stored scene), 0: network output in [-1,1]
 };
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void mesh_points_kernel(const float* __restric
   o[6] = (float)((c + 0.5) / S);
   o[7] = (float)((r + 0.5) / S);
   dpad[(size_t)b * P * P + v] = lin_depth(rgbd, m, b, r, c);
-  flags[(size_t)b * P * P + v] = (pr == 0 || pr == P - 1 || pc == 0 || pc == P - 1) ? 2 : 0;
+  flags[(size_t)b * P * P + v] = (!m.nopad && (pr == 0 || pr == P - 1 || pc == 0 || pc == P - 1)) ? 2 : 0;
   if (pr >= 1 && pr <= S && pc >= 1 && pc <= S) {  // texture = RGB in [0,1], row 0 = image top
     const size_t px = (size_t)(pr - 1) * S + (pc - 1);
 #pragma unroll
@@ -232,7 +234,14 @@ __device__ __forceinline__ Frag eval_frag(const TriSetup& s, double X, double Y)
 #pragma unroll
   for (int k = 0; k < 3; ++k) f.l[k] = s.a[k] * X + s.b[k] * Y + s.c[k];
   f.sum = f.l[0] + f.l[1] + f.l[2];  // = 1 / w_clip at this pixel
-  f.inside = f.l[0] >= 0.0 && f.l[1] >= 0.0 && f.l[2] >= 0.0 && f.sum > 0.0;
+  // top-left fill rule for pixel centres exactly ON an edge (NDC, y up; the gradient (a, b) of an edge function points
+  // inside for either orientation because the functions are divided by det): a left edge (a > 0) or a horizontal top
+  // edge (a == 0, interior below: b < 0) owns its points, the others do not -- a shared edge yields exactly one fragment
+  bool in = f.sum > 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    in = in && (f.l[k] > 0.0 || (f.l[k] == 0.0 && (s.a[k] > 0.0 || (s.a[k] == 0.0 && s.b[k] < 0.0))));
+  f.inside = in;
   const double zndc = f.l[0] * s.zc[0] + f.l[1] * s.zc[1] + f.l[2] * s.zc[2];  // z_clip / w_clip, affine in screen space
   f.inside = f.inside && zndc >= -1.0 && zndc <= 1.0;
   f.depth = (float)(0.5 * zndc + 0.5);
@@ -281,7 +290,7 @@ constexpr int RASTER_SMALL = 256;  // bounding boxes up to this many pixels are 
 __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ verts, const unsigned char* __restrict__ diag,
                                                      int B, int P, const float* __restrict__ mvp, int R,
                                                      unsigned long long* __restrict__ zbuf, int* __restrict__ work,
-                                                     int work_cap) {
+                                                     int work_cap, int nodiscard) {
   const int Q = P - 1, ntri = 2 * Q * Q;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int view = blockIdx.y, b = blockIdx.z;
@@ -300,9 +309,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ v
       return;
     }  // queue full: fall through and walk it here (correct, only slower)
   }
-  float pad[3];
+  float pad[3];   // nodiscard (SimpleRenderer: simple.fsh never discards): the padding test is switched off
 #pragma unroll
-  for (int k = 0; k < 3; ++k) pad[k] = (((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1;
+  for (int k = 0; k < 3; ++k) pad[k] = nodiscard ? 0.f : (float)((((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1);
   unsigned long long* zb = zbuf + mb * R * R;
   const double step = 2.0 / R;
   for (int r = r0; r <= r1; ++r)
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict
                                                          const unsigned char* __restrict__ diag, int B, int P,
                                                          const float* __restrict__ mvp, int R,
                                                          unsigned long long* __restrict__ zbuf,
-                                                         const int* __restrict__ work, int work_cap) {
+                                                         const int* __restrict__ work, int work_cap, int nodiscard) {
   const int Q = P - 1;
   const int count = min(work[0], work_cap);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict
     tri_bbox(s, R, x0, x1, r0, r1);
     float pad[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pad[k] = (((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1;
+    for (int k = 0; k < 3; ++k) pad[k] = nodiscard ? 0.f : (float)((((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1);
     unsigned long long* zb = zbuf + mb * R * R;
     const int tx0 = x0 >> 4, ty0 = r0 >> 4;
     const int ntx = (x1 >> 4) - tx0 + 1, nty = (r1 >> 4) - ty0 + 1;
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
                                                         const float* __restrict__ mvp, int R,
                                                         const unsigned long long* __restrict__ zbuf, float rnear,
                                                         float rfar, unsigned char* __restrict__ color8,
+                                                        float* __restrict__ color_f32,
                                                         float* __restrict__ depth_lin,
                                                         unsigned char* __restrict__ mask_c,
                                                         unsigned char* __restrict__ mask_d) {
@@ -439,11 +449,65 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
   for (int ch = 0; ch < 3; ++ch) {
     const float v = ca > 0.0f ? rgb[ch] / fmaxf(ca, 1e-24f) : 0.0f;
     color8[o * 3 + ch] = (unsigned char)(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);  // to8b (truncating cast), utils.py:34-35
+    if (color_f32) color_f32[o * 3 + ch] = v;   // AggregationRenderer.render's own return value (float colour)
   }
   const float dz = dg > 0.0f ? dr / fmaxf(dg, 1e-24f) : 0.0f;
   depth_lin[o] = rnear * rfar / (rfar - dz * (rfar - rnear));
   mask_c[o] = mc > 0.5f;
   mask_d[o] = md > 0.5f;
+}
+
+// SimpleRenderer (moderngl_renderer.py:11-148, shaders/simple.vsh / simple.fsh): ONE mesh, one depth-tested draw.
+// Per pixel: front-facing fragment -> (NEAREST texel, alpha = edge flag interpolated > 0.999 ? 0 : 1); back-facing ->
+// (0,0,0,0) (its depth still occludes); nothing drawn -> clear colour 0 and clear depth 1.  Read-back math of
+// SimpleRenderer.render (:127-138): mask = alpha > 0.5, depth = near*far / (far - d*(far-near)).
+__global__ __launch_bounds__(256) void simple_shade_kernel(const float* __restrict__ verts,
+                                                           const unsigned char* __restrict__ diag,
+                                                           const float* __restrict__ colors, int B, int S,
+                                                           const float* __restrict__ mvp, int R,
+                                                           const unsigned long long* __restrict__ zbuf, float rnear,
+                                                           float rfar, float* __restrict__ color_f32,
+                                                           float* __restrict__ depth_lin,
+                                                           unsigned char* __restrict__ mask) {
+  const int P = S + 2, Q = P - 1;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (pix >= R * R) return;
+  const int r = pix / R, x = pix - r * R;
+  const double step = 2.0 / R;
+  const double X = (x + 0.5) * step - 1.0, Y = 1.0 - (r + 0.5) * step;
+  const unsigned long long key = zbuf[(size_t)b * R * R + pix];
+  float col[3] = {0.f, 0.f, 0.f}, alpha = 0.f, depth = 1.0f;
+  if (key != ZEMPTY) {
+    const int t = (int)(key & 0xffffffffu);
+    depth = (float)(unsigned)(key >> 32) / 16777215.0f;
+    const float* V = verts + (size_t)b * P * P * 9;
+    const TriSetup s = tri_setup(V, diag + (size_t)b * Q * Q, t, P, mvp + b * 16);
+    if (s.front) {
+      const Frag f = eval_frag(s, X, Y);
+      const double isum = 1.0 / f.sum;
+      float u = 0.f, v = 0.f, fe = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float bw = (float)(f.l[k] * isum);
+        const float* p = V + (size_t)s.vi[k] * 9;
+        u += bw * p[6]; v += bw * p[7];
+        fe += bw * (float)(((int)p[8]) & 1);   // v_is_edge = mod(i_flag, 2)
+      }
+      const int tx = min(max((int)floorf(u * S), 0), S - 1), ty = min(max((int)floorf(v * S), 0), S - 1);
+      const float* tc = colors + (((size_t)b * S + ty) * S + tx) * 3;
+      col[0] = tc[0]; col[1] = tc[1]; col[2] = tc[2];
+      alpha = fe > 0.999f ? 0.0f : 1.0f;
+    }
+  }
+  const size_t o = (size_t)b * R * R + pix;
+  color_f32[o * 3] = col[0]; color_f32[o * 3 + 1] = col[1]; color_f32[o * 3 + 2] = col[2];
+  depth_lin[o] = rnear * rfar / (rfar - depth * (rfar - rnear));
+  mask[o] = alpha > 0.5f;
+}
+
+__global__ __launch_bounds__(256) void to8b_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (unsigned char)(fminf(fmaxf(in[i], 0.f), 1.f) * 255.0f);   // to8b, utils.py:34-35
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,7 +634,8 @@ extern "C" int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv
   m.focal = 0.5 / tan(0.5 * fov);
   m.ppp = 2.0 * tan(0.5 * fov) / S;
   m.nearv = nearv; m.farv = farv; m.atol = atol; m.rtol = rtol; m.erode = erode;
-  m.frustum = padding < 0.f ? 1 : 0; m.padpx = padding; m.metric = input_mode;
+  m.nopad = padding == -2.f ? 1 : 0;
+  m.frustum = (padding < 0.f && !m.nopad) ? 1 : 0; m.padpx = m.nopad ? 0.0 : padding; m.metric = input_mode;
   hipStream_t s = (hipStream_t)stream;
   const int PP = m.P * m.P, QQ = (m.P - 1) * (m.P - 1);
   hipLaunchKernelGGL(mesh_points_kernel, dim3((PP + 255) / 256, B), dim3(256), 0, s, rgbd, m, inv_modelview, verts,
@@ -585,7 +650,7 @@ extern "C" int ivid_warp_render(const float* verts, const unsigned char* diag, c
                                 int NV, int B, int S, const float* mvp, int R, float rnear, float rfar,
                                 unsigned long long* zbuf, unsigned char* color8, float* depth_lin,
                                 unsigned char* mask_color, unsigned char* mask_depth, int* work, int work_cap,
-                                void* stream) {
+                                float* color_f32, void* stream) {
   if (NV <= 0 || B <= 0 || R <= 0) return ivid_set_error("warp_render: bad size", hipSuccess);
   if (work_cap < 0 || (work_cap > 0 && !work)) return ivid_set_error("warp_render: bad work queue", hipSuccess);
   hipStream_t s = (hipStream_t)stream;
@@ -597,12 +662,12 @@ extern "C" int ivid_warp_render(const float* verts, const unsigned char* diag, c
   }
   const int P = S + 2, ntri = 2 * (P - 1) * (P - 1);
   hipLaunchKernelGGL(raster_kernel, dim3((ntri + 255) / 256, NV, B), dim3(256), 0, s, verts, diag, B, P, mvp, R, zbuf,
-                     work, work_cap);
+                     work, work_cap, 0);
   if (work_cap > 0)
     hipLaunchKernelGGL(raster_big_kernel, dim3(work_cap < 8192 ? work_cap : 8192), dim3(256), 0, s, verts, diag, B, P, mvp, R,
-                       zbuf, work, work_cap);
+                       zbuf, work, work_cap, 0);
   hipLaunchKernelGGL(aggregate_kernel, dim3((R * R + 255) / 256, B), dim3(256), 0, s, verts, diag, colors, campos, NV, B,
-                     S, mvp, R, zbuf, rnear, rfar, color8, depth_lin, mask_color, mask_depth);
+                     S, mvp, R, zbuf, rnear, rfar, color8, color_f32, depth_lin, mask_color, mask_depth);
   return ivid_check_launch("warp_render");
 }
 
@@ -629,4 +694,43 @@ extern "C" int ivid_warp_resolve(const unsigned char* color8, const float* depth
   hipLaunchKernelGGL(cond_final_kernel, dim3((SS + 255) / 256, B), dim3(256), 0, s, tmp_small, tmp_dproj, m1, mr0, S,
                      erode, lut255, color, depth, mask, mask_rgb, convex);
   return ivid_check_launch("warp_resolve");
+}
+
+extern "C" int ivid_simple_render(const float* verts, const unsigned char* diag, const float* colors, int B, int S,
+                                  const float* mvp, int R, float rnear, float rfar, unsigned long long* zbuf, int* work,
+                                  int work_cap, float* color_f32, float* depth_lin, unsigned char* mask, void* stream) {
+  if (B <= 0 || R <= 0 || S < 2) return ivid_set_error("simple_render: bad size", hipSuccess);
+  if (work_cap < 0 || (work_cap > 0 && !work)) return ivid_set_error("simple_render: bad work queue", hipSuccess);
+  if (!color_f32 || !depth_lin || !mask || !zbuf) return ivid_set_error("simple_render: null output", hipSuccess);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)B * R * R * sizeof(unsigned long long), s);
+  if (e != hipSuccess) return ivid_set_error("simple_render: memset", e);
+  if (work_cap > 0) {
+    e = hipMemsetAsync(work, 0, 2 * sizeof(int), s);
+    if (e != hipSuccess) return ivid_set_error("simple_render: memset", e);
+  }
+  const int P = S + 2, ntri = 2 * (P - 1) * (P - 1);
+  // simple.fsh never discards (aggregation.fsh drops back-facing skirt fragments): nodiscard = 1
+  hipLaunchKernelGGL(raster_kernel, dim3((ntri + 255) / 256, 1, B), dim3(256), 0, s, verts, diag, B, P, mvp, R, zbuf, work,
+                     work_cap, 1);
+  if (work_cap > 0)
+    hipLaunchKernelGGL(raster_big_kernel, dim3(work_cap < 8192 ? work_cap : 8192), dim3(256), 0, s, verts, diag, B, P, mvp, R,
+                       zbuf, work, work_cap, 1);
+  hipLaunchKernelGGL(simple_shade_kernel, dim3((R * R + 255) / 256, B), dim3(256), 0, s, verts, diag, colors, B, S, mvp, R,
+                     zbuf, rnear, rfar, color_f32, depth_lin, mask);
+  return ivid_check_launch("simple_render");
+}
+
+extern "C" int ivid_resample8_lanczos(const float* color_f32, int B, int R, int S, const int* bounds, const int* coeffs,
+                                      int ksize, unsigned char* tmp_hi8, unsigned char* tmp_h, unsigned char* out8,
+                                      void* stream) {
+  if (B <= 0 || R <= 0 || S <= 0) return ivid_set_error("resample8: bad size", hipSuccess);
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * R * R * 3;
+  hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, color_f32, tmp_hi8, n);
+  hipLaunchKernelGGL(resample8_kernel, dim3((R * S + 255) / 256, B), dim3(256), 0, s, tmp_hi8, R, R, 0, S, bounds, coeffs,
+                     ksize, tmp_h);
+  hipLaunchKernelGGL(resample8_kernel, dim3((S * S + 255) / 256, B), dim3(256), 0, s, tmp_h, R, S, 1, S, bounds, coeffs,
+                     ksize, out8);
+  return ivid_check_launch("resample8");
 }

@@ -31,6 +31,20 @@ def perspective(fovy_rad, aspect, near, far):
     return m
 
 
+def as_matrix(mv):
+    """A modelview in any of the forms callers hold -> 4x4 float32 numpy in math (row, column) order.  numpy arrays /
+    nested lists are taken as they are (math order: what this package's own `look_at` returns).  A PyGLM `mat4` (the
+    reference's type, inference/sample.py:305-336) is COLUMN-major (`m[col][row]`): its `to_list()` is transposed."""
+    if mv is None:
+        return np.eye(4, dtype=np.float32)
+    if hasattr(mv, "to_list") and not isinstance(mv, np.ndarray):
+        return np.asarray(mv.to_list(), dtype=np.float32).T.copy()
+    m = np.asarray(mv, dtype=np.float32)
+    if m.shape != (4, 4):
+        raise ValueError(f"modelview must be 4x4, got {m.shape}")
+    return m
+
+
 def inverse(m):
     return np.linalg.inv(np.asarray(m, dtype=np.float32)).astype(np.float32)
 

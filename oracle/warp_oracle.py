@@ -10,8 +10,12 @@ Pinning status
     imports the reference's own rgbd_3d/utils.py (with stand-ins for the missing glm / cv2 / plyfile
     modules) and stores its outputs; tests compare this restatement against them.
   * 8-bit LANCZOS resolve: PINNED to the real Pillow (the same library the reference calls).
+  * aggregate_conditions' post-processing of the rendered buffers (8-bit LANCZOS, centre-sample depth, 7-of-9
+    masks, depth_edge, erosion): PINNED — tests/golden/make_golden_warp.py runs the reference's own
+    aggregate_conditions on a stub renderer that returns stored hi-res buffers (tests/golden/warp_resolve.npz).
   * rasterisation + shader arithmetic: PARITY UNPINNED — the reference renders with OpenGL through
-    moderngl/EGL, none of which exists offline; oracle/warp_raster.c restates the GL rules.
+    moderngl/EGL, none of which exists offline; oracle/warp_raster.c restates the GL rules (near-plane
+    clipping, top-left fill rule, perspective-correct varyings) in a formulation different from the HIP kernel.
 Missing third-party pieces restated here: PyGLM lookAt/perspective/inverse (GLM's documented
 formulas, float32 like glm.mat4), cv2.erode (min filter whose border never erodes).
 """
@@ -161,7 +165,7 @@ def render(meshes, colors, modelview, fov, S, R, near=0.01, far=200.0):
     L = _lib()
     mvp = (perspective(np.deg2rad(fov), 1.0, near, far) @ np.asarray(modelview, np.float32)).astype(np.float32)
     acc = np.zeros((R * R, 8), dtype=np.float32)
-    skipped = 0
+    clipped = 0
     fp = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
     for mesh, col in zip(meshes, colors):
         v = np.ascontiguousarray(mesh["verts"], np.float32)
@@ -170,17 +174,101 @@ def render(meshes, colors, modelview, fov, S, R, near=0.01, far=200.0):
         cam = np.ascontiguousarray(inverse(mesh["modelview"])[:3, 3], np.float32)
         d24 = np.empty(R * R, np.uint32)
         tri = np.empty(R * R, np.int32)
+        bary = np.zeros((R * R, 3), np.float64)
+        front = np.zeros(R * R, np.uint8)
         m = np.ascontiguousarray(mvp)
-        skipped += L.oracle_raster(fp(v, ctypes.c_float), fp(dg, ctypes.c_ubyte), S, fp(m, ctypes.c_float), R,
-                                   fp(d24, ctypes.c_uint32), fp(tri, ctypes.c_int32))
+        clipped += L.oracle_raster(fp(v, ctypes.c_float), fp(dg, ctypes.c_ubyte), S, fp(m, ctypes.c_float), R,
+                                   fp(d24, ctypes.c_uint32), fp(tri, ctypes.c_int32), fp(bary, ctypes.c_double),
+                                   fp(front, ctypes.c_ubyte))
         L.oracle_shade_aggregate(fp(v, ctypes.c_float), fp(dg, ctypes.c_ubyte), fp(c, ctypes.c_float),
-                                 fp(cam, ctypes.c_float), S, fp(m, ctypes.c_float), R, fp(d24, ctypes.c_uint32),
-                                 fp(tri, ctypes.c_int32), fp(acc, ctypes.c_float))
+                                 fp(cam, ctypes.c_float), S, R, fp(d24, ctypes.c_uint32), fp(tri, ctypes.c_int32),
+                                 fp(bary, ctypes.c_double), fp(front, ctypes.c_ubyte), fp(acc, ctypes.c_float))
     acc = acc.reshape(R, R, 8)
     color = np.where(acc[..., 3:4] > 0.0, acc[..., :3] / np.maximum(acc[..., 3:4], np.float32(1e-24)), np.float32(0.0))
     depth = np.where(acc[..., 5:6] > 0.0, acc[..., 4:5] / np.maximum(acc[..., 5:6], np.float32(1e-24)), np.float32(0.0))
     depth = (np.float32(near) * np.float32(far) / (np.float32(far) - depth * (np.float32(far) - np.float32(near)))).astype(np.float32)
-    return dict(color=color, depth=depth, mask_color=acc[..., 7:8] > 0.5, mask_depth=acc[..., 6:7] > 0.5, skipped=skipped)
+    # clipped = triangles that crossed the near plane (frustum skirt / sheets with a vertex behind the eye): informative
+    return dict(color=color, depth=depth, mask_color=acc[..., 7:8] > 0.5, mask_depth=acc[..., 6:7] > 0.5, clipped=clipped,
+                lowconf=np.logical_and(acc[..., 5] > 0, acc[..., 5] < 1e-7))
+
+
+def _raster(mesh, mvp, S, R, no_discard=False):
+    """One mesh drawn alone: (depth24 uint32 [R*R], tri int32, bary float64 [R*R,3], front uint8, clipped count)."""
+    L = _lib()
+    fp = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    v = np.ascontiguousarray(mesh["verts"], np.float32)
+    if no_discard:   # simple.fsh never discards: hide the padding bit from the rasteriser's back-face test
+        v = v.copy()
+        v[:, 8] = (v[:, 8].astype(np.int32) & ~2).astype(np.float32)
+    dg = np.ascontiguousarray(mesh["diag"], np.uint8)
+    d24, tri = np.empty(R * R, np.uint32), np.empty(R * R, np.int32)
+    bary, front = np.zeros((R * R, 3), np.float64), np.zeros(R * R, np.uint8)
+    m = np.ascontiguousarray(mvp, np.float32)
+    clipped = L.oracle_raster(fp(v, ctypes.c_float), fp(dg, ctypes.c_ubyte), S, fp(m, ctypes.c_float), R,
+                              fp(d24, ctypes.c_uint32), fp(tri, ctypes.c_int32), fp(bary, ctypes.c_double),
+                              fp(front, ctypes.c_ubyte))
+    return d24, tri, bary, front, clipped
+
+
+def _tri_vertex_ids(tri, diag, P):
+    """Vectorised triangulate order (utils.py:113-134): vertex ids [n,3] of triangle ids `tri`."""
+    quad, Q = tri >> 1, P - 1
+    qr, qc = quad // Q, quad % Q
+    i00 = qr * P + qc
+    i01, i10, i11 = i00 + 1, i00 + P, i00 + P + 1
+    ft = diag[quad].astype(bool)
+    even = (tri & 1) == 0
+    return np.stack([np.where(even, i01, i10), np.where(even, i00, i11),
+                     np.where(even, np.where(ft, i11, i10), np.where(ft, i00, i01))], axis=-1)
+
+
+def from_reference_mesh(mesh, S):
+    """A mesh dict of the REFERENCE's depth_to_mesh (vertices.{position,uv,flag[,normal]}, faces, modelview) -> this
+    oracle's arrays (verts [(S+2)^2, 9], diag [(S+1)^2]).  An unpadded S x S mesh (padding=None) is embedded in the
+    padded grid with a ring of COPIES of its border vertices: zero-area triangles, which no rasteriser draws."""
+    vt = mesh["vertices"]
+    pos = np.asarray(vt["position"], np.float32)
+    nrm = np.asarray(vt["normal"], np.float32) if "normal" in vt else np.zeros_like(pos)
+    vb = np.concatenate([pos, nrm, np.asarray(vt["uv"], np.float32), np.asarray(vt["flag"], np.float32).reshape(-1, 1)], -1)
+    faces = np.asarray(mesh["faces"]).reshape(-1, 6)
+    P = S + 2
+    mv = mesh.get("modelview")
+    mv = np.eye(4, dtype=np.float32) if mv is None else np.asarray(mv, np.float32)
+    if vb.shape[0] == P * P:
+        idx = np.arange(P * P).reshape(P, P)
+        ft = faces[:, 2] == idx[1:, 1:].ravel()
+        return dict(verts=vb, diag=ft.astype(np.uint8), modelview=mv)
+    assert vb.shape[0] == S * S, vb.shape
+    idx = np.arange(S * S).reshape(S, S)
+    ft = (faces[:, 2] == idx[1:, 1:].ravel()).reshape(S - 1, S - 1)
+    vb = np.pad(vb.reshape(S, S, 9), ((1, 1), (1, 1), (0, 0)), "edge").reshape(P * P, 9)
+    diag = np.zeros((P - 1, P - 1), np.uint8)
+    diag[1:-1, 1:-1] = ft
+    return dict(verts=vb, diag=diag.ravel(), modelview=mv)
+
+
+def simple_render(mesh, color, modelview, fov, S, R, near=0.01, far=200.0):
+    """SimpleRenderer.render for one target view (moderngl_renderer.py:96-148; simple.vsh / simple.fsh): colour
+    [R,R,3] fp32, depth [R,R,1] fp32 (linearised window depth, `far` where nothing was drawn), mask [R,R,1] bool."""
+    mvp = (perspective(np.deg2rad(fov), 1.0, near, far) @ np.asarray(modelview, np.float32)).astype(np.float32)
+    d24, tri, bary, front, _ = _raster(mesh, mvp, S, R, no_discard=True)
+    P = S + 2
+    hit = tri >= 0
+    vi = _tri_vertex_ids(np.where(hit, tri, 0), np.asarray(mesh["diag"], np.uint8), P)
+    V = np.asarray(mesh["verts"], np.float32)
+    bw = bary.astype(np.float32)
+    u = (bw * V[vi, 6]).sum(-1, dtype=np.float32)
+    v = (bw * V[vi, 7]).sum(-1, dtype=np.float32)
+    fe = (bw * (V[vi, 8].astype(np.int32) & 1).astype(np.float32)).sum(-1, dtype=np.float32)
+    tx = np.clip(np.floor(u * np.float32(S)).astype(np.int64), 0, S - 1)
+    ty = np.clip(np.floor(v * np.float32(S)).astype(np.int64), 0, S - 1)
+    ff = hit & (front > 0)
+    col = np.where(ff[:, None], np.asarray(color, np.float32)[ty, tx], np.float32(0.0))
+    alpha = np.where(ff & ~(fe > 0.999), 1.0, 0.0)
+    d = np.where(hit, d24.astype(np.float32) / np.float32(16777215.0), np.float32(1.0)).astype(np.float32)
+    n, f = np.float32(near), np.float32(far)
+    depth = (n * f / (f - d * (f - n))).astype(np.float32)
+    return dict(color=col.reshape(R, R, 3).astype(np.float32), depth=depth.reshape(R, R, 1), mask=(alpha > 0.5).reshape(R, R, 1))
 
 
 def depth_edge(depth, atol, rtol):

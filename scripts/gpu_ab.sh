@@ -1,10 +1,17 @@
 #!/bin/bash
-# A/B of two library builds on ONE box (box-to-box variance is several %): ab/lib_a.so vs the in-tree library.
+# A/B on ONE box: bench.py (headline only) for each library in LIBS (paths relative to the repo root; "-" = the product lib).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for rep in 1 2; do
-  for v in a b; do
-    if [ $v = a ]; then export IVID_HIP_LIB=$PWD/ab/lib_a.so; else unset IVID_HIP_LIB; fi
-    echo "== $v (rep $rep)"
-    RES=${RES:-0} CFGS=${CFGS:--1,2} SHAPES_ONLY=${SHAPES_ONLY:-0,1,8} REPS=10 python scripts/conv_bench.py 2>&1 | grep -v amdgpu
-  done
+mkdir -p gpurun_out
+for rep in 1 ${REPS:-}; do
+for lib in ${LIBS:-- ab/libivid_oldfused.so}; do
+  tag=$(basename "$lib" .so)
+  [ "$lib" = "-" ] && unset IVID_HIP_LIB || export IVID_HIP_LIB="$PWD/$lib"
+  IVID_BENCH_LAYERS=gpurun_out/layers_${tag}.json timeout 600 python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-parity-mode ${BENCH_ARGS:-} > gpurun_out/ab_${tag}.json 2> gpurun_out/ab_${tag}.err
+  echo "== $tag rep $rep exit $?"
+  python - "$tag" <<'PY'
+import json, sys
+r = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
+print(r["value"], r["ms_per_step"], r["mfma_roofline_frac_whole_step"], r.get("kernel_time_ms_per_forward"))
+PY
+done
 done

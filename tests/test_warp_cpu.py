@@ -59,7 +59,7 @@ def test_oracle_reprojection_identity():
     mv = WC.orbit(0.0, 0.0)
     mesh, col = WC.oracle_mesh(rgbd[0], mv)
     res = W.render([mesh], [col], mv, 45, S, R)
-    assert res["skipped"] == 0
+    assert res["clipped"] == 0
     assert res["mask_depth"].mean() > 0.85          # everything but discontinuity sheets
     hw = rgbd[0].transpose(1, 2, 0) * 0.5 + 0.5
     depth_src = W.linearize_depth(hw[:, :, 3:], 0.6, 5.0)
@@ -81,3 +81,70 @@ def test_oracle_novel_view_has_holes_and_hull():
     assert 0.2 < out["mask"].mean() < 0.98                               # disocclusions appear
     assert (out["mask_rgb"] <= out["mask"]).all()                        # colour mask is a subset of the depth mask
     assert out["depth_convex"][out["mask"] > 0].min() > 0
+
+
+def test_oracle_resolve_equals_the_references_own_aggregate_conditions():
+    """tests/golden/warp_resolve.npz: outputs of /root/reference's aggregate_conditions run on a stub renderer that
+    returns the stored hi-res buffers (make_golden_warp.py) -- the restatement must reproduce them exactly."""
+    g = C.load_golden("warp_resolve")
+    for tag in ("S32x3", "S16x5", "S32x3_wide"):
+        S, ssaa, erode = (int(v) for v in g[f"{tag}_cfg"])
+        hi = {k: g[f"{tag}_in_{k}"] for k in ("color", "depth", "mask_color", "mask_depth")}
+        out = W.resolve(hi, S, ssaa, 0.6, 5.0, 0.03, 0.03, erode)
+        for k in ("color", "depth", "mask", "mask_rgb", "depth_convex"):
+            assert np.array_equal(np.asarray(out[k], np.float64), np.asarray(g[f"{tag}_out_{k}"], np.float64)), (tag, k)
+        assert 0.02 < g[f"{tag}_out_mask"].mean() < 0.98
+
+
+def test_oracle_rasteriser_clips_triangles_behind_the_eye():
+    """A target camera INSIDE the source frustum's skirt region: skirt / sheet triangles have vertices with w <= 0.  The
+    clipped rasterisation must stay finite, and must agree with an unclipped evaluation wherever no clipping happened
+    (same scene from a far camera: clipped == 0)."""
+    S, R = 32, 96
+    rgbd = WC.synthetic_rgbd(S, 9, layers=True)
+    mesh, col = WC.oracle_mesh(rgbd[0], WC.orbit(0.0, 0.0))
+    near_cam = W.look_at((0.05, 0.02, 0.35), (0.0, 0.0, -1.0), (0, 1, 0))      # well inside the unit sphere
+    res = W.render([mesh], [col], near_cam, 45, S, R)
+    assert res["clipped"] > 0
+    assert np.isfinite(res["depth"]).all() and np.isfinite(res["color"]).all()
+    assert 0.05 < res["mask_depth"].mean() <= 1.0
+    far = W.render([mesh], [col], WC.orbit(0.6, 0.15), 45, S, R)
+    assert far["clipped"] == 0 and far["lowconf"].mean() > 0.01                 # skirt / sheets visible as low-confidence hull
+
+
+def test_oracle_fill_rule_gives_every_pixel_of_a_shared_edge_to_exactly_one_triangle():
+    """Identity view at SSAA 3: mesh vertices project EXACTLY onto target pixel centres (u = (i + 0.5)/S = (3i + 1.5)/(3S)),
+    so quad edges and diagonals run through pixel centres -- with the top-left rule the covered area is still exactly the
+    image (no double hits are observable, but no gaps either)."""
+    S, R = 16, 48
+    z = np.full((S, S, 1), 1.0)
+    rgbd = np.concatenate([np.full((S, S, 3), 0.5), W.project_depth(z, 0.6, 5.0)], -1).astype(np.float32)
+    rgbd = (rgbd * 2 - 1).transpose(2, 0, 1)
+    mv = W.look_at((0, 0, 1), (0, 0, 0), (0, 1, 0))
+    mesh, col = WC.oracle_mesh(rgbd, mv)
+    res = W.render([mesh], [col], mv, 45, S, R)
+    md = res["mask_depth"][..., 0]
+    # the height field spans the pixel centres 1 .. R-2 (source pixel i sits on target pixel 3i+1); the half-pixel rim is
+    # frustum skirt (low confidence).  Inside, every pixel is confident: none is lost on a shared edge ...
+    assert md[1:R - 2, 1:R - 2].all()
+    assert np.abs(res["depth"][1:R - 2, 1:R - 2] - 1.0).max() < 1e-4
+    # ... and nowhere in the image is a pixel left without a fragment (surface or skirt)
+    assert (md | res["lowconf"]).all()
+
+
+def test_oracle_simple_render_and_unpadded_mesh_embedding():
+    """SimpleRenderer semantics on the oracle side (used as the rasteriser of the reference's forward_backward_warp in
+    make_golden_warp.py): an UNPADDED reference mesh is embedded with a ring of copies (zero-area triangles); rendered
+    from its own camera it returns the source depth at the pixel centres it covers."""
+    g = C.load_golden("warp_mesh")
+    S, R = 16, 48
+    vb, faces = g["vbo_nopad_16"], g["faces_nopad_16"]
+    ref_mesh = dict(vertices=dict(position=vb[:, 0:3], uv=vb[:, 3:5], flag=vb[:, 5:6]), faces=faces, modelview=g["modelview_16"])
+    m = W.from_reference_mesh(ref_mesh, S)
+    assert m["verts"].shape == ((S + 2) ** 2, 9) and m["diag"].shape == ((S + 1) ** 2,)
+    col = g["rgbd_16"][0, :3].transpose(1, 2, 0) * 0.5 + 0.5
+    out = W.simple_render(m, col, g["modelview_16"], 45, S, R, 0.1, 200.0)
+    centre, ok = out["depth"][1::3, 1::3, 0], out["mask"][1::3, 1::3, 0]
+    assert ok.mean() > 0.3                                    # all but discontinuity triangles (alpha 0; plenty at S = 16)
+    assert np.abs(centre[ok] - g["depth_lin_16"][..., 0][ok]).max() < 2e-3
+    assert out["depth"].max() > 150.0                         # the unpadded mesh leaves a rim of background (clear depth -> far)
