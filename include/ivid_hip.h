@@ -181,6 +181,9 @@ int ivid_ddpm_step(const float* x_t, const float* eps_c, const float* eps_u, con
  * cat[x(4), mask_rgb(1, if given), y_rgb*m_rgb + n_rgb*(1-m_rgb) (3), y_d*m + n_d*(1-m) (1), mask(1)]. */
 int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const float* mask_rgb, const float* noise_rgb,
                       const float* noise_depth, float* out, int B, int HW, void* stream);
+/* SuperResCFG.make_cond_inputs (sr_cfg.py:23-36): out[B,Cx+Cy,S,S] = cat[x[B,Cx,S,S], bilinear x(S/s) upsample of
+ * y[B,Cy,s,s] with align_corners=False] (fp32 NCHW), torch's upsample_bilinear2d arithmetic. */
+int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int Cy, int S, int s, void* stream);
 
 /* ---- RGBD depth-warp conditioning (replaces rgbd_3d + the moderngl/OpenGL renderer) ----
  * Step 1, per generated view: depth -> textured grid mesh with frustum skirt (rgbd_3d/utils.py:144-260

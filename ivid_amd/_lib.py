@@ -63,6 +63,7 @@ SIGNATURES = {
     "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ivid_ddpm_step": (i32, [vp, vp, vp, C.POINTER(DdpmCoef), vp, vp, vp, i32, i32, vp]),
     "ivid_inpaint_cond": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ivid_sr_cond": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ivid_mesh_build": (i32, [vp, i32, i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float,
                               i32, vp, vp, vp, vp, vp, vp]),
     "ivid_warp_render": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32,

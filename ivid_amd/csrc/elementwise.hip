@@ -253,6 +253,37 @@ extern "C" int ivid_ddpm_step(const float* x_t, const float* eps_c, const float*
   return ivid_check_launch("ddpm_step");
 }
 
+// SuperResCFG.make_cond_inputs (sr_cfg.py:23-36): out = cat[x, bilinear_up(y, scale, align_corners=False)] along channels.
+// torch's upsample_bilinear2d arithmetic: src = max((dst + 0.5) / scale - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, n - 1),
+// lambda = src - i0, value = (1-ly) * ((1-lx) v00 + lx v01) + ly * ((1-lx) v10 + lx v11), all in fp32.
+__global__ __launch_bounds__(256) void sr_cond_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      float* __restrict__ out, int Cx, int Cy, int S, int s) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (p >= S * S) return;
+  const int r = p / S, c = p - r * S;
+  const float rs = (float)s / (float)S;   // 1 / scale
+  const float fy = fmaxf(((float)r + 0.5f) * rs - 0.5f, 0.f), fx = fmaxf(((float)c + 0.5f) * rs - 0.5f, 0.f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, s - 1), x1 = min(x0 + 1, s - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const size_t HW = (size_t)S * S, hw = (size_t)s * s;
+  float* o = out + (size_t)n * (Cx + Cy) * HW + p;
+  for (int ch = 0; ch < Cx; ++ch) o[(size_t)ch * HW] = x[((size_t)n * Cx + ch) * HW + p];
+  for (int ch = 0; ch < Cy; ++ch) {
+    const float* q = y + ((size_t)n * Cy + ch) * hw;
+    const float v = hy * (hx * q[(size_t)y0 * s + x0] + lx * q[(size_t)y0 * s + x1]) +
+                    ly * (hx * q[(size_t)y1 * s + x0] + lx * q[(size_t)y1 * s + x1]);
+    o[(size_t)(Cx + ch) * HW] = v;
+  }
+}
+
+extern "C" int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int Cy, int S, int s, void* stream) {
+  if (B <= 0 || Cx <= 0 || Cy <= 0 || S <= 0 || s <= 0 || S % s) return ivid_set_error("sr_cond: S must be a multiple of s", hipSuccess);
+  hipLaunchKernelGGL(sr_cond_kernel, dim3((S * S + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, y, out, Cx, Cy, S, s);
+  return ivid_check_launch("sr_cond");
+}
+
 extern "C" int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const float* mask_rgb,
                                  const float* noise_rgb, const float* noise_depth, float* out, int B, int HW,
                                  void* stream) {

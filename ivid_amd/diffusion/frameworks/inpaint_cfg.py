@@ -23,8 +23,12 @@ class InpaintCFG(GaussianDiffusion):
         n_rgb = noise_fn((b, 3, h, w)).float().contiguous()
         n_d = noise_fn((b, 1, h, w)).float().contiguous()
         out = torch.empty(b, 10 if mask_rgb is not None else 9, h, w, dtype=torch.float32, device=x.device)
-        x, y, mask = x.float().contiguous(), y.float().contiguous(), mask.float().contiguous()
-        mr = mask_rgb.float().contiguous() if mask_rgb is not None else None
+        # the kernel reads fixed layouts through raw pointers: broadcast exactly like the reference's tensor expressions
+        # would (e.g. a [1,1,H,W] mask), refuse anything else instead of reading out of bounds
+        x = x.float().contiguous()
+        y = y.float().expand(b, 4, h, w).contiguous()
+        mask = mask.float().expand(b, 1, h, w).contiguous()
+        mr = mask_rgb.float().expand(b, 1, h, w).contiguous() if mask_rgb is not None else None
         _lib.call("ivid_inpaint_cond", _lib.ptr(x), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(mr), _lib.ptr(n_rgb),
                   _lib.ptr(n_d), _lib.ptr(out), b, h * w, torch.cuda.current_stream(x.device).cuda_stream)
         return out

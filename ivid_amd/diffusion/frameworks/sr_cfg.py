@@ -1,8 +1,8 @@
 """SuperResCFG (reference: diffusion/frameworks/sr_cfg.py:11-60): condition = bilinear x(S/s)
 upsample of the low-resolution RGBD (align_corners=False) concatenated behind x."""
 import torch
-import torch.nn.functional as F
 
+from ... import _lib
 from .gaussian_diffusion import GaussianDiffusion, cfg_branches, cfg_combine
 
 
@@ -12,10 +12,14 @@ class SuperResCFG(GaussianDiffusion):
         self.p_uncond = p_uncond
 
     def make_cond_inputs(self, x, y, **kwargs):
-        # sr_cfg.py:31-36.  The resize runs once per step on [B,4,s,s]; it is plumbing next to the UNet.
-        scale = x.shape[-1] // y.shape[-1]
-        y = F.interpolate(y, scale_factor=scale, mode="bilinear", align_corners=False)
-        return torch.cat([x, y], dim=1)
+        """sr_cfg.py:31-36 as one HIP kernel (ivid_sr_cond): bilinear upsample of y (align_corners=False) + channel concat."""
+        b, cx, S, _ = x.shape
+        y = y.float().expand(b, -1, -1, -1).contiguous()
+        x = x.float().contiguous()
+        out = torch.empty(b, cx + y.shape[1], S, S, dtype=torch.float32, device=x.device)
+        _lib.call("ivid_sr_cond", _lib.ptr(x), _lib.ptr(y), _lib.ptr(out), b, cx, y.shape[1], S, y.shape[-1],
+                  torch.cuda.current_stream(x.device).cuda_stream)
+        return out
 
     @torch.no_grad()
     def eps_branches(self, x, t, y, classes=None, strength=3.0, **kwargs):

@@ -65,12 +65,15 @@ class DdimSampler:
         eps_c, eps_u, strength = self.framework.eps_branches(x_t, t_model, classes=classes, **kwargs)
         rgb = rgb_m = dep = dep_m = convex = None
         w_rgb = w_dep = w_con = -1.0
+        # raw pointers with fixed layouts go to the kernel: broadcast like the reference's tensor expressions would
+        # (ddim.py:88-95), refuse shapes that cannot be (a multi-channel mask has no counterpart in the fused step)
+        ex = lambda tns, ch: as_f32(tns.expand(b, ch, h, w))
         if replace_rgb is not None:          # tested with `is not None` in the reference (ddim.py:86)
-            w_rgb, rgb, rgb_m = float(replace_rgb[0]), as_f32(replace_rgb[1]), as_f32(replace_rgb[2])
+            w_rgb, rgb, rgb_m = float(replace_rgb[0]), ex(replace_rgb[1], 3), ex(replace_rgb[2], 1)
         if replace_depth:                    # tested by truthiness in the reference (ddim.py:90)
-            w_dep, dep, dep_m = float(replace_depth[0]), as_f32(replace_depth[1]), as_f32(replace_depth[2])
+            w_dep, dep, dep_m = float(replace_depth[0]), ex(replace_depth[1], 1), ex(replace_depth[2], 1)
             if constrain_depth:
-                w_con, convex = float(constrain_depth[0]), as_f32(constrain_depth[1])
+                w_con, convex = float(constrain_depth[0]), ex(constrain_depth[1], 1)
         k = self._coef(ti, tpi, eta, strength, clip_denoised, w_rgb, w_dep, w_con)
         # the reference draws randn_like(x_t) every step even when eta == 0 (ddim.py:101): an injected
         # noise stream must advance identically; the on-device generator is only consulted when used

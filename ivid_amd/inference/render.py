@@ -3,8 +3,8 @@
 Same CLI flags and defaults.  Per scene: load_scene -> meshes rebuilt on the GPU (numeric padding 32) -> every frame of
 the camera trajectory is one `WarpRenderer.render` at SSAA 5 (640^2, near 0.1 / far 200, render.py:62-64) -> 8-bit
 quantise + Pillow LANCZOS to 128^2 and inferno-coloured projected depth, exactly the reference's post-processing
-(:73-84).  imageio/ffmpeg are not dependencies here: frames are written as an animated GIF (+ the first frame as PNG)
-instead of an mp4."""
+(:73-84).  Videos: `<scene>.mp4` / `<scene>_depth.mp4` at 30 fps like render.py:87-88 through an `ffmpeg` executable (or
+imageio) when present; an animated GIF otherwise (utils.write_video)."""
 import argparse
 import glob
 import os
@@ -13,7 +13,7 @@ import numpy as np
 
 from .. import rgbd_3d
 from ..rgbd_3d import camera
-from .utils import colorize_depth, load_scene, scene_to_renderer
+from .utils import colorize_depth, read_scene, scene_to_renderer, write_video
 
 
 def trajectory(name, frames, num_scenes, rng=None):
@@ -67,7 +67,7 @@ def main(argv=None):
     mvs = trajectory(opt.traj, opt.frames, len(scenes))
     ssaa, renderer = 5, None
     for i, path in enumerate(scenes):
-        scene = load_scene(path)
+        scene = read_scene(path)
         S = scene[0]["color"].shape[0]
         if renderer is None or renderer.max_views < len(scene) or renderer.image_size != S:
             renderer = rgbd_3d.WarpRenderer(1, S, ssaa, max(27, len(scene)), near=0.1, far=200.0)
@@ -78,9 +78,7 @@ def main(argv=None):
             Image.fromarray(colors[0]).save(os.path.join(opt.output_dir, "results", f"{name}.png"))
         else:
             for arr, suffix in ((colors, ""), (depths, "_depth")):
-                frames = [Image.fromarray(a) for a in arr]
-                frames[0].save(os.path.join(opt.output_dir, "videos", f"{name}{suffix}.gif"), save_all=True,
-                               append_images=frames[1:], duration=33, loop=0)
+                write_video(os.path.join(opt.output_dir, "videos", f"{name}{suffix}.mp4"), arr, fps=30)
 
 
 if __name__ == "__main__":

@@ -1,9 +1,11 @@
 """inference/utils.py helpers of the reference that the sampling path needs (parse_int_list :13-22, colorize_depth
-:25-41, reorder :44-55, save_scene / load_scene :74-113) plus PIL-based image writers (the reference uses imageio /
-torchvision / cv2, which are not dependencies here)."""
+:25-41, reorder :44-55, save_scene / load_scene :74-113) plus PIL-based image writers and a video writer (the reference
+uses imageio / torchvision / cv2, which are not dependencies here)."""
 import io
 import os
 import re
+import shutil
+import subprocess
 
 import numpy as np
 import torch
@@ -63,12 +65,11 @@ _INFERNO = None
 
 
 def _inferno_lut():
-    """cv2.COLORMAP_INFERNO as RGB uint8 [256,3]: OpenCV's table is matplotlib's 256-entry inferno data scaled by 255 and
-    rounded (cv2 is not installed here, so this equality is by construction of both tables, not pinned by a run)."""
+    """cv2.COLORMAP_INFERNO as RGB uint8 [256,3] (committed table, see inferno_lut.py)."""
     global _INFERNO
     if _INFERNO is None:
-        import matplotlib
-        _INFERNO = np.round(np.asarray(matplotlib.colormaps["inferno"](np.arange(256))[:, :3]) * 255).astype(np.uint8)
+        from .inferno_lut import INFERNO_RGB
+        _INFERNO = np.asarray(INFERNO_RGB, dtype=np.uint8)
     return _INFERNO
 
 
@@ -100,46 +101,114 @@ def _png_array(b):
     return np.asarray(Image.open(io.BytesIO(b)))
 
 
-def save_scene(path, views, modelviews, fov=45, near=0.6, far=5):
+def _as_glm(mv):
+    """Modelview for the scene file: a `glm.mat4` when PyGLM is importable -- the type the reference pickles and whose
+    consumers call `glm.inverse` on (inference/utils.py:90-101, moderngl_renderer.py:309) -- else a float32 [4,4] array in
+    math (row, column) order.  glm.mat4 is column-major: the 16 scalars are passed column by column."""
+    m = np.asarray(mv, dtype=np.float32).reshape(4, 4)
+    try:
+        import glm
+    except ImportError:
+        return m
+    return glm.mat4(*[float(v) for v in m.T.reshape(-1)])
+
+
+def _from_glm(mv):
+    """glm.mat4 (column-major, `to_list()` = list of columns) or array -> float32 [4,4] in math order."""
+    if hasattr(mv, "to_list") and not isinstance(mv, np.ndarray):
+        return np.asarray(mv.to_list(), dtype=np.float32).T.copy()
+    return np.asarray(mv, dtype=np.float32).reshape(4, 4)
+
+
+def save_scene(path, meshes, colors, fov=45, near=0.6, far=5):
     """The reference's scene file (inference/utils.py:74-100): np.savez_compressed(path, data=[{color, depth, fov,
     modelview}, ...]) with `color` = PNG bytes of the 8-bit RGB image and `depth` = PNG bytes of the float32 METRIC depth
-    reinterpreted as RGBA8.  views: [V,4,S,S] network output in [-1,1]; the metric depth is linearize_depth of the
-    z-buffer channel in float32, exactly what the reference's meshes carry (sample.py:126-131).
-    Difference: `modelview` is stored as a float32 [4,4] array in math order (the reference pickles a glm.mat4; PyGLM is
-    not a dependency here).  load_scene accepts both."""
-    v = views.detach().float().cpu().numpy().transpose(0, 2, 3, 1) * 0.5 + 0.5                    # sample.py:126
+    reinterpreted as RGBA8.  Two call forms:
+      save_scene(path, meshes, colors)                    the reference's: meshes = depth_to_mesh dicts (.depth, .fov,
+                                                          .modelview), colors = [S,S,3] float arrays in [0,1]
+      save_scene(path, views, modelviews, fov, near, far) the sampling driver's: views [V,4,S,S] network output in [-1,1]
+                                                          (the metric depth is linearize_depth of the z-buffer channel in
+                                                          float32, what the reference's meshes carry, sample.py:126-131)
+    `modelview` is stored as glm.mat4 when PyGLM is installed (readable by the reference's own load_scene / render.py),
+    else as a float32 [4,4] array in math order; load_scene here accepts both."""
     data = []
-    for i in range(v.shape[0]):
-        color = np.clip(v[i, :, :, :3] * 255, 0, 255).astype(np.uint8)                             # utils.py:77
-        d = np.clip(v[i, :, :, 3:], 1e-6, 1.0 - 1e-6)
-        depth = np.ascontiguousarray((near * far / (far - (far - near) * d)).astype(np.float32))   # linearize_depth
+    if isinstance(meshes, torch.Tensor):
+        v = meshes.detach().float().cpu().numpy().transpose(0, 2, 3, 1) * 0.5 + 0.5                # sample.py:126
+        modelviews = colors
+        for i in range(v.shape[0]):
+            color = np.clip(v[i, :, :, :3] * 255, 0, 255).astype(np.uint8)                          # utils.py:77
+            d = np.clip(v[i, :, :, 3:], 1e-6, 1.0 - 1e-6)
+            depth = np.ascontiguousarray((near * far / (far - (far - near) * d)).astype(np.float32))  # linearize_depth
+            data.append((color, depth, fov, modelviews[i]))
+    else:
+        for mesh, col in zip(meshes, colors):
+            color = np.clip(np.asarray(col) * 255, 0, 255).astype(np.uint8)
+            data.append((color, np.ascontiguousarray(np.asarray(mesh["depth"]).astype(np.float32)), mesh["fov"], mesh["modelview"]))
+    out = []
+    for color, depth, f, mv in data:
         s = depth.shape[0]
-        data.append({"color": _png_bytes(color), "depth": _png_bytes(np.frombuffer(depth, dtype=np.uint8).reshape(s, s, 4)),
-                     "fov": fov, "modelview": np.asarray(modelviews[i], dtype=np.float32).reshape(4, 4)})
+        out.append({"color": _png_bytes(color), "depth": _png_bytes(np.frombuffer(depth, dtype=np.uint8).reshape(s, s, 4)),
+                    "fov": f, "modelview": _as_glm(_from_glm(mv))})
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    np.savez_compressed(path, data=np.array(data, dtype=object))
+    np.savez_compressed(path, data=np.array(out, dtype=object))
 
 
-def load_scene(path):
-    """-> list of views {color [S,S,3] float in [0,1] (8-bit / 255), depth [S,S,1] float32 metric, fov, modelview [4,4]}
-    (the decoded content of inference/utils.py:103-113; the meshes are rebuilt on the GPU by scene_to_renderer)."""
+def read_scene(path):
+    """Decoded content of a scene file: list of views {color [S,S,3] float in [0,1] (8-bit / 255), depth [S,S,1] float32
+    metric, fov, modelview float32 [4,4] math order}.  No GPU needed."""
     data = np.load(path, allow_pickle=True)["data"]
     out = []
     for d in data:
         color = _png_array(d["color"])
         s = color.shape[0]
         depth = np.frombuffer(np.ascontiguousarray(_png_array(d["depth"])), dtype=np.float32).reshape(s, s, 1)
-        mv = d["modelview"]
-        mv = np.asarray(mv.to_list(), dtype=np.float32).T if hasattr(mv, "to_list") else np.asarray(mv, dtype=np.float32)
-        out.append({"color": color / 255, "depth": depth, "fov": d["fov"], "modelview": mv.reshape(4, 4)})
+        out.append({"color": color / 255, "depth": depth, "fov": d["fov"], "modelview": _from_glm(d["modelview"])})
     return out
 
 
+def load_scene(path, atol=0.03, rtol=0.03, erode_rgb=3):
+    """inference/utils.py:103-113, same return: (meshes, colors) with meshes = depth_to_mesh(depth, 32, fov, modelview,
+    atol, rtol, erode_rgb, cal_normal=True) per stored view (built on the GPU) and colors = [S,S,3] float in [0,1]."""
+    from .. import rgbd_3d
+    views = read_scene(path)
+    meshes = [rgbd_3d.utils.depth_to_mesh(v["depth"], 32, v["fov"], v["modelview"], atol=atol, rtol=rtol, erode_rgb=erode_rgb,
+                                          cal_normal=True) for v in views]
+    return meshes, [v["color"] for v in views]
+
+
 def scene_to_renderer(renderer, scene, atol=0.03, rtol=0.03, erode_rgb=3):
-    """Rebuild the meshes of a loaded scene inside a WarpRenderer (batch 1): load_scene's depth_to_mesh(depth, 32, fov,
-    modelview, atol, rtol, erode_rgb, cal_normal=True) (inference/utils.py:108-111), on the GPU."""
+    """The device-resident form of load_scene: rebuild the meshes of a decoded scene (read_scene) inside a WarpRenderer
+    (batch 1) without a host round trip per mesh."""
     renderer.reset()
     for v in scene:
         rgbd = np.concatenate([v["color"].astype(np.float32), v["depth"].astype(np.float32)], axis=-1)
         t = torch.from_numpy(np.ascontiguousarray(rgbd.transpose(2, 0, 1)[None]))
         renderer.add_view(t, v["modelview"], v["fov"], atol=atol, rtol=rtol, erode_rgb=erode_rgb, padding=32, metric=True)
+
+
+def write_video(path, frames, fps=30):
+    """`imageio.mimsave(path.mp4, frames, fps=30)` of inference/render.py:87-88 without imageio: raw RGB frames piped into
+    an `ffmpeg` executable (libx264, yuv420p) when one is on PATH; else imageio if it imports; else an animated GIF next to
+    the requested name.  frames: uint8 [F,H,W,3].  Returns the path actually written."""
+    frames = np.ascontiguousarray(np.asarray(frames, dtype=np.uint8))
+    f, h, w, _ = frames.shape
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    exe = shutil.which("ffmpeg")
+    if exe is not None:
+        cmd = [exe, "-y", "-loglevel", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{w}x{h}", "-r", str(fps), "-i", "-",
+               "-an", "-vcodec", "libx264", "-pix_fmt", "yuv420p", path]
+        p = subprocess.run(cmd, input=frames.tobytes(), capture_output=True)
+        if p.returncode == 0:
+            return path
+        print("ffmpeg failed, falling back:", p.stderr.decode(errors="replace")[-300:])
+    try:
+        import imageio
+        imageio.mimsave(path, list(frames), fps=fps)
+        return path
+    except ImportError:
+        pass
+    from PIL import Image
+    gif = os.path.splitext(path)[0] + ".gif"
+    imgs = [Image.fromarray(a) for a in frames]
+    imgs[0].save(gif, save_all=True, append_images=imgs[1:], duration=int(round(1000 / fps)), loop=0)
+    return gif

@@ -38,7 +38,7 @@ def test_load_scene_round_trip(tmp_path):
     views = _views(V=2, S=8, seed=3)
     path = str(tmp_path / "s.npz")
     U.save_scene(path, views, [np.eye(4), np.eye(4)], 45, 0.6, 5)
-    sc = U.load_scene(path)
+    sc = U.read_scene(path)
     assert len(sc) == 2
     assert sc[0]["color"].shape == (8, 8, 3) and sc[0]["color"].max() <= 1.0 and sc[0]["color"].min() >= 0.0
     assert sc[0]["depth"].shape == (8, 8, 1) and sc[0]["depth"].dtype == np.float32
@@ -62,7 +62,85 @@ def test_load_scene_accepts_glm_like_modelviews(tmp_path):
     data = np.load(path, allow_pickle=True)["data"]
     data[0]["modelview"] = FakeMat4(m)
     np.savez_compressed(path, data=data)
-    assert np.array_equal(U.load_scene(path)[0]["modelview"], m)
+    assert np.array_equal(U.read_scene(path)[0]["modelview"], m)
+
+
+def test_save_scene_writes_glm_mat4_when_pyglm_is_importable(tmp_path, monkeypatch):
+    """inference/utils.py:90-101 pickles meshes[i].modelview, a glm.mat4, and the reference's own render.py hands it to
+    glm.inverse (moderngl_renderer.py:309).  With a `glm` module present the file must carry mat4 objects (column-major),
+    and they must come back as the same math-order matrix."""
+    import sys
+    import types
+
+    class mat4:                                   # the slice of PyGLM's mat4 that matters: 16 column-major scalars in, to_list out
+        def __init__(self, *a):
+            assert len(a) == 16
+            self.cols = np.asarray(a, dtype=np.float32).reshape(4, 4)     # cols[c][r]
+
+        def to_list(self):
+            return self.cols.tolist()
+
+    fake = types.ModuleType("glm")
+    fake.mat4 = mat4
+    fake.inverse = lambda m: mat4(*np.linalg.inv(m.cols.T).T.reshape(-1))
+    monkeypatch.setitem(sys.modules, "glm", fake)
+    test_save_scene_writes_glm_mat4_when_pyglm_is_importable.mat4 = mat4   # picklable by reference
+    globals()["mat4"] = mat4
+    mat4.__module__, mat4.__qualname__ = __name__, "mat4"
+    m = np.array([[1, 2, 3, 4], [0, 1, 0, 5], [0, 0, 1, 6], [0, 0, 0, 1]], dtype=np.float32)
+    path = str(tmp_path / "glm.npz")
+    U.save_scene(path, _views(V=1, S=8), [m], 45, 0.6, 5)
+    stored = np.load(path, allow_pickle=True)["data"][0]["modelview"]
+    assert isinstance(stored, mat4)
+    assert np.array_equal(stored.cols[3, :3], m[:3, 3])                    # column 3 of a column-major mat4 = the translation
+    inv = fake.inverse(stored)                                             # what the reference does with it
+    assert np.allclose(np.asarray(inv.to_list()).T, np.linalg.inv(m), atol=1e-6)
+    assert np.array_equal(U.read_scene(path)[0]["modelview"], m)
+
+
+def test_save_scene_reference_call_form(tmp_path):
+    """save_scene(path, meshes, colors) as inference/sample.py:156,166 calls it: meshes carry .depth (metric), .fov, .modelview."""
+    S = 8
+    depth = np.linspace(0.7, 4.0, S * S, dtype=np.float64).reshape(S, S, 1)
+    col = np.random.default_rng(0).uniform(0, 1, (S, S, 3))
+    mesh = dict(depth=depth, fov=45, modelview=np.eye(4, dtype=np.float32))
+    path = str(tmp_path / "ref.npz")
+    U.save_scene(path, [mesh], [col])
+    sc = U.read_scene(path)
+    assert np.array_equal(sc[0]["depth"], depth.astype(np.float32)) and sc[0]["fov"] == 45
+    assert np.array_equal(sc[0]["color"], np.clip(col * 255, 0, 255).astype(np.uint8) / 255)
+
+
+def test_reorder_matches_the_references_literal_index_list():
+    order = [23, 17, 11, 5, 2, 8, 14, 20, 26, 21, 15, 9, 3, 0, 6, 12, 18, 24, 22, 16, 10, 4, 1, 7, 13, 19, 25]   # utils.py:49-51
+    x = [torch.full((1, 2, 2), float(i)) for i in range(27)]
+    out = U.reorder(x, "3x9")
+    assert out.shape == (27, 1, 2, 2) and [int(v[0, 0, 0]) for v in out] == order
+    y = U.reorder(x[1:], "3x9")                      # 26 conditioning images: a blank (-1) view 0 is prepended (:46-47)
+    assert [int(v[0, 0, 0]) for v in y] == [o if o else -1 for o in order]
+    assert U.parse_int_list("1,2,5-10") == [1, 2, 5, 6, 7, 8, 9, 10] and U.parse_int_list("0-8") == list(range(9))
+
+
+def test_write_video_pipes_raw_frames_to_ffmpeg(tmp_path, monkeypatch):
+    """render.py:87-88 writes <scene>.mp4 at 30 fps.  Without imageio the frames go to an `ffmpeg` executable as raw rgb24;
+    a stand-in executable records its arguments and stdin."""
+    import os
+    import stat
+    fake = tmp_path / "bin" / "ffmpeg"
+    fake.parent.mkdir()
+    fake.write_text("#!/bin/sh\nfor a; do last=$a; done\necho \"$@\" > \"$last.args\"\ncat > \"$last\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ["PATH"])
+    frames = np.random.default_rng(1).integers(0, 256, (5, 16, 24, 3), dtype=np.uint8)
+    out = U.write_video(str(tmp_path / "videos" / "a.mp4"), frames, fps=30)
+    assert out.endswith("a.mp4") and open(out, "rb").read() == frames.tobytes()
+    args = open(out + ".args").read()
+    assert "-s 24x16" in args and "-r 30" in args and "rgb24" in args and "libx264" in args
+    # no ffmpeg, no imageio: an animated GIF with the same frames
+    monkeypatch.setenv("PATH", str(tmp_path / "nowhere"))
+    out2 = U.write_video(str(tmp_path / "videos" / "b.mp4"), frames, fps=30)
+    from PIL import Image
+    assert out2.endswith("b.gif") and Image.open(out2).n_frames == 5
 
 
 def test_colorize_depth_matches_the_reference_mapping():
@@ -71,7 +149,11 @@ def test_colorize_depth_matches_the_reference_mapping():
     assert isinstance(c, torch.Tensor) and c.shape == (3, 16, 16)
     lut = U._inferno_lut()
     assert lut.shape == (256, 3) and lut.dtype == np.uint8
-    assert tuple(lut[0]) == (0, 0, 4) and tuple(lut[255]) == (252, 255, 164)    # inferno end points
+    assert tuple(lut[0]) == (0, 0, 4) and tuple(lut[255]) == (252, 255, 164)    # inferno end points #000004 / #fcffa4
+    assert tuple(lut[128]) == (188, 55, 84)                                     # inferno(0.5) = #bc3754
+    import matplotlib                                                           # the committed table = OpenCV's conversion of
+    ref = np.round(np.asarray(matplotlib.colormaps["inferno"](np.arange(256))[:, :3]) * 255).astype(np.uint8)   # matplotlib's data
+    assert np.array_equal(lut, ref)
     # depth -1 (near) -> index 255 (bright), depth +1 (far) -> index 0 (dark): utils.py:33-34
     assert np.allclose((c[:, 0, 0].numpy() + 1) / 2 * 255, lut[255], atol=1e-4)
     assert np.allclose((c[:, -1, -1].numpy() + 1) / 2 * 255, lut[0], atol=1e-4)

@@ -65,8 +65,12 @@ def test_scene_file_round_trip_and_free_view_render(tmp_path):
     views = torch.from_numpy(np.concatenate([WC.synthetic_rgbd(S, 3, smooth_color=True), WC.synthetic_rgbd(S, 3, smooth_color=True)]))
     path = str(tmp_path / "scenes" / "scene_test.npz")
     U.save_scene(path, views, mvs, 45, 0.6, 5.0)
-    scene = U.load_scene(path)
+    scene = U.read_scene(path)
     assert len(scene) == 2 and scene[0]["color"].shape == (S, S, 3) and scene[0]["depth"].dtype == np.float32
+    # the reference's load_scene form: (meshes, colors), meshes = depth_to_mesh(depth, 32, ..., cal_normal=True)
+    meshes, cols = U.load_scene(path)
+    assert len(meshes) == 2 and meshes[0].vertices.position.shape == ((S + 2) ** 2, 3) and "normal" in meshes[0].vertices
+    assert np.array_equal(cols[0], scene[0]["color"])
     rr = WarpRenderer(1, S, 5, 4, near=0.1, far=200.0)
     colors, depths = R.render_scene(rr, scene[:1], [mvs[0], WC.orbit(0.1, 0.0)], ssaa=5)
     assert colors.shape == (2, S, S, 3) and depths.shape == (2, S, S, 3) and colors.dtype == np.uint8
@@ -76,6 +80,31 @@ def test_scene_file_round_trip_and_free_view_render(tmp_path):
     assert err.mean() < 3.0 and np.quantile(err, 0.95) < 12.0
     tr = R.trajectory("swing", 60, 1)
     assert len(tr) == 60 and np.allclose(tr[0], WC.orbit(0.6, 0.0), atol=1e-6)
+
+
+def test_free_view_frame_ssaa5_matches_the_c_rasteriser():
+    """One frame of inference/render.py (SSAA 5, near 0.1 / far 200, a load_scene mesh with numeric padding 32) through the
+    reference-contract AggregationRenderer vs the C rasteriser on the SAME reference-built mesh (tests/golden/warp_mesh.npz:
+    the live reference's depth_to_mesh(depth, 32, ...))."""
+    from ivid_amd import rgbd_3d
+    g = C.load_golden("warp_mesh")
+    S, ssaa = 32, 5
+    vb = g["vbo_pad32_32"]
+    mesh = dict(vertices=dict(position=vb[:, 0:3], normal=vb[:, 3:6], uv=vb[:, 6:8], flag=vb[:, 8:9]), faces=g["faces_pad32_32"],
+                modelview=g["modelview_32"])
+    col = g["rgbd_32"][0, :3].transpose(1, 2, 0) * 0.5 + 0.5
+    rr = rgbd_3d.AggregationRenderer(S * ssaa, S, near=0.1, far=200, device=0)
+    for k, tgt in enumerate([WC.orbit(-0.4, 0.1), WC.orbit(0.6 * np.cos(1.0), 0.15 * np.sin(1.0))]):
+        got = rr.render([mesh], [col], tgt, 45)
+        ref = W.render([W.from_reference_mesh(mesh, S)], [col], tgt, 45, S, S * ssaa, near=0.1, far=200.0)
+        md, rd = got.mask_depth[..., 0], ref["mask_depth"][..., 0]
+        iou = (md & rd).sum() / max((md | rd).sum(), 1)
+        both = md & rd
+        drel = np.abs(got.depth[..., 0][both] - ref["depth"][..., 0][both]) / ref["depth"][..., 0][both]
+        cd = np.abs(got.color[both] - ref["color"][both]).max(-1)
+        G.report(f"warp/free_view_ssaa5_{k}", iou=iou, depth_rel_p999=float(np.quantile(drel, 0.999)), color_exact=float((cd < 1e-6).mean()),
+                 coverage=float(md.mean()))
+        assert iou > 0.99 and np.quantile(drel, 0.999) < 1e-2 and (cd < 1e-6).mean() > 0.99
 
 
 def test_mesh_build_full_size_batch_matches_oracle():
@@ -181,6 +210,18 @@ def test_render_per_sample_cameras_batch3():
     src1 = np.stack([WC.orbit(0.2, 0.1), WC.orbit(-0.35, 0.0), WC.orbit(0.5, -0.12)])
     tgt = np.stack([WC.orbit(-0.3, -0.1), WC.orbit(0.25, 0.15), WC.orbit(-0.1, 0.05)])
     _compare_render(32, 3, [src0, src1], tgt, "per_sample_B3", B=3, layers=[False, True])
+
+
+def test_render_target_camera_inside_the_scene_clips_behind_the_eye():
+    """A free-view camera well inside the unit sphere (inference/render.py trajectories can go there): skirt / sheet
+    triangles then have vertices BEHIND the eye (w <= 0).  The HIP kernel evaluates them with 2-D homogeneous edge functions
+    and no clipping; the oracle clips them against the near plane -- both must draw the same pixels."""
+    near_cam = W.look_at((0.05, 0.02, 0.35), (0.0, 0.0, -1.0), (0, 1, 0))
+    S, R = 32, 96
+    mesh, col = WC.oracle_mesh(WC.synthetic_rgbd(S, 10, layers=True)[0], WC.orbit(0.0, 0.0))
+    assert W.render([mesh], [col], near_cam, 45, S, R)["clipped"] > 0        # the case really is exercised
+    _compare_render(S, 3, [WC.orbit(0.0, 0.0), WC.orbit(0.3, 0.0)], near_cam, "inside_S32", B=2, layers=[True, False],
+                    bars=(0.99, 0.98, 2e-2, 0.99))
 
 
 def test_resolve_kernels_match_the_references_own_aggregate_conditions():
