@@ -77,6 +77,7 @@ class AdmUnet2d(nn.Module):
             precision = "fp16" if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
+        self.max_plans = int(os.environ.get("IVID_MAX_PLANS", "3"))
         self.tile_cfg = int(os.environ.get("IVID_TILE_CFG", "0"))
 
         # ---- parameters: same names / shapes / init statistics as the reference ----
@@ -165,10 +166,19 @@ class AdmUnet2d(nn.Module):
         return self._packed
 
     def plan(self, batch, stacked=False):
+        """Launch plan (activation arena + hipGraph) for one (batch, stacked-CFG) shape.  At most `max_plans` are kept,
+        least recently used first out: a ragged last batch (e.g. 10 000 samples in batches of 32 leave one of 16) builds a
+        second arena, but a stream of distinct batch sizes cannot pile arenas up (each is GBs at bs 64)."""
         key = (batch, stacked)
-        if key not in self._plans:
-            self._plans[key] = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
-        return self._plans[key]
+        p = self._plans.pop(key, None)
+        if p is None:
+            while len(self._plans) >= self.max_plans:
+                old = self._plans.pop(next(iter(self._plans)))      # dict order = recency (re-inserted on every hit)
+                torch.cuda.synchronize(self.device)                 # its buffers may still be in flight
+                del old
+            p = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
+        self._plans[key] = p
+        return p
 
     # ---- reference-compatible forward ----
     @torch.no_grad()

@@ -145,3 +145,63 @@ def test_install_aliases_reference_package_names():
         for k in [k for k in sys.modules if k == "diffusion" or k.startswith("diffusion.") or k == "rgbd_3d"]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_unsupported_attention_geometry_is_refused_at_construction():
+    """csrc/attn.hip is written for head dim 64 and T % 64 == 0: any other configuration must fail loudly at build_spec
+    time instead of striding the qkv tensor wrongly."""
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    with pytest.raises(NotImplementedError):
+        AdmUnet2d(**dict(C.MINI, num_head_channels=-1, num_heads=1))         # the constructor defaults: head dim = C
+    with pytest.raises(NotImplementedError):
+        AdmUnet2d(**dict(C.MINI, num_head_channels=32))
+    with pytest.raises(NotImplementedError):
+        AdmUnet2d(**dict(C.MINI, image_size=24, attention_resolutions=[6]))  # T = 36
+    AdmUnet2d(**C.MINI)
+
+
+def test_precision_names_and_reference_fp16_api():
+    from ivid_amd import _lib
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}
+    hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
+    for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
+        assert re.search(rf"#define {name} {code}\b", hdr)
+    m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
+    assert m.precision == "fp16" and m.dtype == torch.float16          # adm.py:333: the reference's attribute
+    m.convert_to_fp32(); assert m.precision == "fp32"
+    m.convert_to_fp16(); assert m.precision == "fp16"
+    m.set_precision("bf16x3"); assert m.precision == "bf16x3"
+    with pytest.raises(ValueError):
+        m.set_precision("int8")
+
+
+def test_split_pack_layout_is_hi_then_lo_per_eight_channels():
+    """IVID_BF16X3 weight operand (include/ivid_hip.h): 32 bytes per 8 K values = 8 x bf16 hi, 8 x bf16 lo; hi + lo
+    reproduces the fp32 weight to 2^-17."""
+    from ivid_amd.diffusion.backbones.plan import split_pack
+    w = C.seeded_randn(3, 5, 32) * 0.37
+    p = split_pack(w)
+    assert p.dtype == torch.bfloat16 and p.shape == (5, 64)
+    q = p.view(5, 4, 2, 8).float()
+    hi, lo = q[:, :, 0].reshape(5, 32), q[:, :, 1].reshape(5, 32)
+    assert torch.equal(hi, w.bfloat16().float())
+    assert float(((hi + lo) - w).abs().max() / w.abs().max()) < 2 ** -16
+
+
+def test_cfg_branches_follow_the_reference_for_every_sign_of_strength():
+    """classifier_free_guidance.py:39-42 with a CPU stand-in backbone: s > 0 two branches, s = 0 plain eps_c, s < 0 scaled
+    eps_c and still one forward; classes None -> unconditional."""
+    from ivid_amd.diffusion.frameworks.gaussian_diffusion import cfg_branches, cfg_combine
+    calls = []
+
+    def backbone(x, t, classes=None):
+        calls.append(classes is not None)
+        return x * (2.0 if classes is not None else 3.0)
+    x, t, cls = torch.ones(2, 1), torch.zeros(2), torch.tensor([1, 2])
+    for s, want, ncalls in ((1.5, (1 + 1.5) * 2.0 - 1.5 * 3.0, 2), (0.0, 2.0, 1), (-0.25, 0.75 * 2.0, 1)):
+        calls.clear()
+        out = cfg_combine(*cfg_branches(backbone, x, t, cls, s))
+        assert torch.allclose(out, torch.full((2, 1), want)) and len(calls) == ncalls, s
+    calls.clear()
+    assert torch.allclose(cfg_combine(*cfg_branches(backbone, x, t, None, 3.0)), torch.full((2, 1), 3.0)) and calls == [False]

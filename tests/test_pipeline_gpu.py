@@ -128,3 +128,38 @@ def test_sample_all_chain_against_the_cpu_oracle_chain():
         errs[f"view{j}"] = C.rel_l2(got[:, j], prev[j])
     G.report("chain/sample_all_vs_oracle", **errs, **cond_close)
     assert all(e < 1e-3 for e in errs.values()), errs
+
+
+def test_cli_main_writes_the_reference_output_tree(tmp_path):
+    """inference/sample.py `main` (sample.py:179-338) end to end on one GPU at mini scale: reference-format config JSONs and
+    checkpoints (bare state_dicts written with torch.save) in, the reference's output tree out (results/ grids/ conds/
+    scenes/ under viewset_<..>_steps_u<..>_c<..>_guidance<..>, file names class<ccc>_seed<sssss>), scene files readable."""
+    import json
+    import os
+    from ivid_amd.inference import sample as S_, utils as U
+    cfgs = {}
+    for tag, args, fw, fwargs, seed in (("uncond", C.MINI, "ClassifierFreeGuidance", {"p_uncond": 0.1}, 0),
+                                        ("cond", C.MINI_COND, "InpaintCFG", {"p_uncond": 0.1, "p_uncond_img": 0}, 2)):
+        cfg = {"backbone": {"name": "AdmUnet2d", "args": dict(args, use_fp16=True)},
+               "framework": {"name": fw, "args": dict(timesteps=1000, beta_schedule="linear", **fwargs)}}
+        cfgs[tag] = str(tmp_path / f"{tag}.json")
+        json.dump(cfg, open(cfgs[tag], "w"))
+        torch.save(C.synth_weights(args, seed), str(tmp_path / f"{tag}.pt"))
+    out = str(tmp_path / "out")
+    argv = ["--config_uncond", cfgs["uncond"], "--config_cond", cfgs["cond"], "--ckpt_uncond", str(tmp_path / "uncond.pt"),
+            "--ckpt_cond", str(tmp_path / "cond.pt"), "--output_dir", out, "--seeds", "3,5-6", "--classes", "mod", "--viewset", "3x9",
+            "--steps_uncond", "3", "--steps_cond", "2", "--guidance", "0.5", "--batchsize", "2", "--erode_rgb", "1"]
+    S_.main(argv)
+    root = os.path.join(out, "viewset_3x9_steps_u3_c2_guidance0.5")
+    for seed in (3, 5, 6):
+        name = f"class{seed % 10:03d}_seed{seed:05d}"
+        for sub, f in (("grids", f"rgb_{name}.png"), ("grids", f"depth_{name}.png"), ("conds", f"rgb_cond_{name}.png"),
+                       ("conds", f"depth_cond_{name}.png"), ("scenes", f"scene_{name}.npz")):
+            assert os.path.isfile(os.path.join(root, sub, f)), (sub, f)
+        scene = U.read_scene(os.path.join(root, "scenes", f"scene_{name}.npz"))
+        assert len(scene) == 27 and scene[0]["color"].shape == (32, 32, 3) and scene[26]["modelview"].shape == (4, 4)
+    from PIL import Image
+    g = Image.open(os.path.join(root, "grids", "rgb_class003_seed00003.png"))
+    assert g.size == (9 * 32, 3 * 32)                       # 3 rows x 9 columns (reorder + nrow 9, sample.py:161-165)
+    # the models came up in the reference's precision for use_fp16 configs
+    assert S_.parse_int_list("3,5-6") == [3, 5, 6]
