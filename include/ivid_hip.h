@@ -55,8 +55,9 @@ int ivid_event_destroy(void* ev);
  *   res_mode  : 0 none; 1 add res[N,H,W,Cout]; 2 add nearest-x2-upsampled res[N,H/2,W/2,Cout];
  *               3 add 2x2-avg-pooled res[N,2H,2W,Cout]  (ResBlock2d skip through x_upd, adm.py:203-208,222)
  *   out_mode  : 0 NHWC dtype [N,H,W,Cout]; 1 fp32 NCHW [N,Cout,H,W] (final conv, adm.py:566)
- *   tile_cfg  : 0 auto, 1 = 128x128 tile / 4 waves, 2 = 256x256 tile / 8 waves, 3 = 128x32 tile (narrow Cout);
- *               +8 = also prefetch the next channel chunk into L2 (experiment: measured 5-15 % slower, off by default)
+ *   tile_cfg  : 0 auto; 1 = 128x128 tile / 4 waves; 2 = 256x256 / 8 waves (wide layers); 3 = 128x32 (Cout <= 32: the
+ *               4-channel output conv); 4 = 512x128 / 8 waves (Cout <= 128: the small / SR models' first levels at the
+ *               256x256 tile's LDS-read : MFMA ratio); 5 = 128x64 / 4 waves (tiny problems that leave CUs idle with tile 1)
  *   stats     : NULL, or fp32 [N*H*W/blk][Cout][2]: per block of blk consecutive pixels and output channel, sum and sum
  *               of squares of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this
  *               epilogue (same layout as ivid_gn_partial with H*W/blk chunks per image); blk =

@@ -48,7 +48,7 @@ struct ConvArgs {
   float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool PF>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const ConvArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -59,8 +59,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
-  static_assert(!PF || NT == 2 * BM, "prefetch mapping assumes two threads per tile row");
-  constexpr int PF_LDS = PF ? NT * 4 : 0;  // scratch landing zone of the L2-prefetch loads (never read)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,27 +107,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     b_ptr[i] = (co < p.Cout) ? p.w + ((size_t)co * Ktot + c) * sizeof(T) : nullptr;
   }
 
-  // L2 prefetch (PF): PMC showed the waves parked ~1/3 of the time in s_waitcnt/barrier although 90 % of the tile
-  // loads hit in L2 — every K-step waits for its SLOWEST load, i.e. for the compulsory HBM misses.  So each thread
-  // touches one 64-byte half of one tile row of the SAME tap `pf_dist` channel chunks ahead with a fire-and-forget
-  // 4-byte LDS-DMA into a scratch slab: by the time the real loads come, the lines sit in the XCD's L2.
-  const char* pf_base0 = nullptr;
-  const char* pf_base1 = nullptr;
-  int pf_y = -0x40000000, pf_x = 0;
-  if constexpr (PF) {
-    const int row = tid % BM, half = tid / BM;
-    const int m = m0 + row;
-    if (m < p.M) {
-      const int n = m / HW, rem = m - n * HW;
-      pf_y = rem / p.W;
-      pf_x = rem - pf_y * p.W;
-    }
-    const int mm = m < p.M ? m : 0;
-    pf_base0 = p.src0 + (size_t)mm * p.C0 * sizeof(T) + half * 64;
-    pf_base1 = p.src1 ? p.src1 + (size_t)mm * p.C1 * sizeof(T) + half * 64 : p.zero;
-  }
-  const int pf_dist = p.taps == 9 ? 1 : 4;  // chunks ahead (>= ~8 K-steps of lead time)
-
   // K-loop order: channel-chunk-major, taps inner — the 9 shifted re-reads of one 128-byte channel slab are back to
   // back, so they hit in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the whole channel extent of
   // the tile once per tap.  (The order must be a compile-time property: a runtime switch here made hipcc place an
@@ -160,14 +137,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     for (int i = 0; i < B_IT; ++i) {
       const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
       glds16(g, sB + (i * NT + wave * 64) * 16);
-    }
-    if constexpr (PF) {
-      const int pc = cbase + pf_dist * BKE;          // first channel of the prefetched chunk
-      const bool same_src = second ? pc < Ctot : pc < p.C0;   // stay inside the current source tensor
-      const bool inb = (unsigned)(pf_y + dy) < (unsigned)p.H && (unsigned)(pf_x + dx) < (unsigned)p.W;
-      const char* g = (second ? pf_base1 : pf_base0) + delta + pf_dist * 128;
-      g = (inb && same_src) ? g : p.zero;
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_addr_of(smem + 2 * STAGE + wave * 256)) : "memory");
     }
     if (++ld_tap == p.taps) {
       ld_tap = 0;
@@ -209,15 +178,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
 
   issue(0);
   for (int kt = 0; kt < nk; ++kt) {
-    if constexpr (PF) {
-      // counted wait: everything but the newest VMEM op (the prefetch, issued last) has landed; raw barrier, because
-      // __syncthreads() would drain vmcnt to 0 and put the prefetch's HBM latency back on the critical path
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    } else {
-      wait_vmcnt0();
-      __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
-    }
+    wait_vmcnt0();
+    __syncthreads();  // stage kt&1 landed for every wave; everyone finished reading the other stage
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + A_BYTES;
     // the first fragments are requested BEFORE the next stage's 8 LDS-DMA loads are issued, so their LDS latency
@@ -272,8 +234,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   }
 
   // ---------------- epilogue ----------------
-  wait_vmcnt0();    // (PF) no LDS-DMA may still be in flight when the slabs are reused
-  __syncthreads();  // all waves done with the operand stages; LDS is reused as per-wave slabs
+  __syncthreads();  // all waves done with the operand stages (every DMA was waited for in the loop); LDS is reused as per-wave slabs
   constexpr int LDC = WTN + 4;  // floats per slab row (pad keeps the two half-waves on different banks)
   float* slab = (float*)smem + wave * (32 * LDC);
   const int Cout = p.Cout;
@@ -420,17 +381,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool PF>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   ConvArgs a = a0;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
-  constexpr int SMEM = ((2 * STAGE > EPI) ? 2 * STAGE : EPI) + (PF ? NT * 4 : 0);
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
   const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
   a.ntiles_n = nt;
   a.ntiles_total = mt * nt;
-  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, PF>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -442,6 +404,27 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Tile of a launch (tile_cfg 0 = auto).  Per-wave tiles and what they cost in LDS reads per MFMA (the limiter of this
+// kernel: 128 B/clk/CU of ds_read against 4 SIMDs of MFMA):
+//   2: 256 x 256, 8 waves 2x4, wave 128 x 64  (6 reads / 8 MFMA)   wide layers whenever >= 1.5 rounds of workgroups exist
+//   4: 512 x 128, 8 waves 8x1, wave  64 x 128 (6 reads / 8 MFMA)   Cout <= 128 (the small / SR models' first levels): the same
+//                                                                   read:MFMA ratio as tile 2 instead of tile 1's 4 / 4
+//   1: 128 x 128, 4 waves 2x2, wave  64 x 64  (4 reads / 4 MFMA)   everything else; two workgroups per CU
+//   5: 128 x 64,  4 waves 2x2, wave  64 x 32  (3 reads / 2 MFMA)   tiny problems (8^2 levels at small batch): twice the
+//                                                                   workgroups of tile 1 when that one leaves CUs idle
+//   3: 128 x 32,  4 waves 4x1                                       Cout <= 32 (the 4-channel output conv)
+static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg) {
+  int cfg = tile_cfg & 7;
+  if (cfg != 0) return cfg;
+  if (Cout <= 32) return 3;
+  const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
+  if (Cout >= 256 && big >= 384) return 2;
+  if (Cout <= 128 && Cout > 64 && (M + 511) / 512 >= 256) return 4;
+  const long long mid = ((M + 127) / 128) * ((Cout + 127) / 128);
+  if (mid < 256 && Cout >= 64) return 5;
+  return 1;
+}
 
 extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
                            const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
@@ -464,21 +447,19 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
   a.stats = stats;
   hipStream_t s = (hipStream_t)stream;
-  if ((tile_cfg & 7) == 0) {  // auto: big tile when it still fills the chip; narrow tile for the 4-channel output conv
-    const long long big = (long long)((a.M + 255) / 256) * ((Cout + 255) / 256);
-    tile_cfg = (tile_cfg & 8) | (Cout <= 32 ? 3 : ((Cout >= 256 && big >= 384) ? 2 : 1));
-  }
+  tile_cfg = ivid_conv_pick_tile(a.M, Cout, tile_cfg);
+  if (tile_cfg < 1 || tile_cfg > 5) return ivid_set_error("conv: tile_cfg must be 0 (auto) .. 5", hipSuccess);
   if (stats) {  // a statistics block must not straddle two images
-    const int gran = (tile_cfg & 7) == 3 ? 32 : 64;
+    const int gran = tile_cfg == 3 ? 32 : 64;
     if (out_mode != 0 || (H * W) % gran) return ivid_set_error("conv: stats need NHWC output and H*W % block == 0", hipSuccess);
   }
-  const bool pf = (tile_cfg & 8) != 0;   // bit 3 of tile_cfg ENABLES the L2 prefetch (measured slower: off by default)
-  tile_cfg &= 7;
-#define IVID_CONV_DISPATCH(TT)                                                        \
-  do {                                                                                \
-    if (tile_cfg == 2) return pf ? launch_conv<TT, 256, 256, 2, 4, true>(a, s) : launch_conv<TT, 256, 256, 2, 4, false>(a, s); \
-    if (tile_cfg == 3) return pf ? launch_conv<TT, 128, 32, 4, 1, true>(a, s) : launch_conv<TT, 128, 32, 4, 1, false>(a, s);   \
-    return pf ? launch_conv<TT, 128, 128, 2, 2, true>(a, s) : launch_conv<TT, 128, 128, 2, 2, false>(a, s);                    \
+#define IVID_CONV_DISPATCH(TT)                                             \
+  do {                                                                     \
+    if (tile_cfg == 2) return launch_conv<TT, 256, 256, 2, 4>(a, s);       \
+    if (tile_cfg == 3) return launch_conv<TT, 128, 32, 4, 1>(a, s);        \
+    if (tile_cfg == 4) return launch_conv<TT, 512, 128, 8, 1>(a, s);       \
+    if (tile_cfg == 5) return launch_conv<TT, 128, 64, 2, 2>(a, s);        \
+    return launch_conv<TT, 128, 128, 2, 2>(a, s);                          \
   } while (0)
   if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);
   if (dtype == IVID_F16) IVID_CONV_DISPATCH(_Float16);
@@ -489,11 +470,5 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
 
 // Pixels per GroupNorm-statistics block that ivid_conv2d will write for this problem (depends on the tile it picks).
 extern "C" int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg) {
-  int cfg = tile_cfg & 7;
-  if (cfg == 0) {
-    const long long M = (long long)N * H * W;
-    const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
-    cfg = Cout <= 32 ? 3 : ((Cout >= 256 && big >= 384) ? 2 : 1);
-  }
-  return cfg == 3 ? 32 : 64;
+  return ivid_conv_pick_tile((long long)N * H * W, Cout, tile_cfg) == 3 ? 32 : 64;
 }

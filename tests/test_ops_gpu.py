@@ -78,6 +78,11 @@ CONV_CASES = [
     ("3x3_bigtile_512tiles_res", 8, 128, 128, 64, 0, 256, 3, 1, 0, 2),
     ("3x3_narrow_nchw_out4", 2, 32, 32, 128, 0, 4, 3, 0, 1, 3),
     ("3x3_narrow_auto_c32", 1, 16, 16, 64, 0, 32, 3, 1, 0, 0),
+    ("3x3_tile512x128_res", 2, 32, 32, 128, 0, 128, 3, 1, 0, 4),
+    ("3x3_tile512x128_mtail_concat", 3, 24, 24, 64, 64, 96, 3, 0, 0, 4),
+    ("1x1_tile512x128_auto_big_m", 8, 128, 128, 64, 0, 128, 1, 0, 0, 0),
+    ("3x3_tile128x64_res_up", 2, 16, 16, 128, 0, 192, 3, 2, 0, 5),
+    ("3x3_tile128x64_auto_tiny", 4, 8, 8, 128, 0, 256, 3, 1, 0, 0),
 ]
 
 
