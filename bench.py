@@ -55,10 +55,18 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default="bf16", choices=sorted(DTYPE_CODE))
     ap.add_argument("--parity-precision", default="bf16x3", choices=sorted(DTYPE_CODE),
                     help="second, parity-grade mode timed beside the headline ('none' via --no-parity-mode)")
+    ap.add_argument("--extra-precisions", default="fp16",
+                    help="comma list of further modes timed briefly beside the headline (fp16 = the reference's use_fp16 torso)")
     ap.add_argument("--guidance", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+                    help="c2 (default): BASELINE config 2, the headline metric.  c3: BASELINE config 3 end to end -- large uncond "
+                         "(1000-step DDPM, CFG) + large cond (50-step DDIM, InpaintCFG) on the `random` viewset with the HIP "
+                         "depth-warp in the loop, bs 32: samples/s and the share of the time spent outside the UNet")
+    ap.add_argument("--c3-steps-uncond", type=int, default=1000)
+    ap.add_argument("--c3-steps-cond", type=int, default=50)
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="initialise the ranks, all_gather (rank, device), print ranks_seen and exit (CPU/gloo test of the launcher)")
     return ap.parse_args(argv)
@@ -218,6 +226,9 @@ def main():
     from ivid_amd.diffusion import frameworks, samplers
     from ivid_amd.diffusion.backbones import AdmUnet2d
 
+    if a.config == "c3":
+        return bench_c3(a, rank, world, dev, C, parallel, dist)
+
     margs = dict({"large": C.LARGE128, "small": C.SMALL128, "sr256": C.SR256}[a.model])
     S = margs["image_size"]
     schema = C.schema_for(margs)
@@ -366,25 +377,32 @@ def main():
                 json.dump(rows, f, indent=0)
         result["forward_ms_eager_events"] = round(total_ms, 3)
 
-    # ---- the parity-grade mode, timed beside the headline on the same workload (every rank, same fences) ----
-    if not a.no_parity_mode and a.parity_precision != a.precision:
-        pp = a.parity_precision
+    # ---- the parity-grade mode (and further modes), timed beside the headline on the same workload (every rank, same fences) ----
+    extra = [] if a.no_parity_mode else [a.parity_precision] + [p for p in a.extra_precisions.split(",") if p]
+    extra = [p for i, p in enumerate(extra) if p != a.precision and p in DTYPE_CODE and p not in extra[:i]]
+    modes = {}
+    for pp in extra:
         model.set_precision(pp)
         psteps = max(2, min(a.steps, 5))
         pdt = timed(psteps, 2)
         pf = fwd_per_step * psteps * world / pdt
         ptf = pf * B * gflop / 1e3
-        result["parity_mode"] = {"dtype": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
-                                 "ms_per_step": round(1e3 * pdt / psteps, 3), "job_tflops": round(ptf, 2),
-                                 "frac": round(ptf / world / PEAK_TFLOPS[pp], 4),
-                                 "frac_note": "algorithmic FLOPs / dense bf16 MFMA peak (the 3 MFMAs per product are overhead)"}
-        model.set_precision(a.precision)
-        if rank == 0:
-            dev_tab = rel_l2_vs_reference([a.precision, pp])
-            if dev_tab:
-                result["rel_l2_vs_reference"] = round(dev_tab[a.precision], 6)
-                result["parity_mode"]["rel_l2_vs_reference"] = round(dev_tab[pp], 8)
-                result["parity_mode"]["reference_output"] = "tests/golden/%s.npz (live reference, fp32 CPU)" % golden[0]
+        modes[pp] = {"dtype": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
+                     "ms_per_step": round(1e3 * pdt / psteps, 3), "job_tflops": round(ptf, 2),
+                     "frac": round(ptf / world / PEAK_TFLOPS[pp], 4)}
+    model.set_precision(a.precision)
+    if extra and rank == 0:
+        dev_tab = rel_l2_vs_reference([a.precision] + extra)
+        if dev_tab:
+            result["rel_l2_vs_reference"] = round(dev_tab[a.precision], 6)
+            for pp in extra:
+                modes[pp]["rel_l2_vs_reference"] = round(dev_tab[pp], 8)
+                modes[pp]["reference_output"] = "tests/golden/%s.npz (live reference, fp32 CPU)" % golden[0]
+    if a.parity_precision in modes:
+        result["parity_mode"] = dict(modes.pop(a.parity_precision),
+                                     frac_note="algorithmic FLOPs / dense bf16 MFMA peak (the 3 MFMAs per product are overhead)")
+    if modes:
+        result["other_modes"] = list(modes.values())
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:   # reported at N = 1 only (a host-side figure)
         result["cpu_baseline"] = cpu_baseline(C, margs, has_cls, a.model, B, result["unit"])
@@ -395,6 +413,104 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_c3(a, rank, world, dev, C, parallel, dist):
+    """BASELINE config 3 (SURVEY.md §8d "C3"): one batch of 32 samples per rank through the whole iterative loop of
+    inference/sample.py with the `random` viewset (2 views per sample: unconditional + one warped/inpainted view):
+    large uncond model, 1000-step DDPM with CFG (2 x 1000 forwards) -> depth_to_mesh -> aggregate_conditions at the second
+    camera (HIP z-buffer warp) -> large cond model, 50-step DDIM with InpaintCFG (2 x 50 forwards).  Synthetic weights.
+    Prints samples/s end to end and the share of the wall time not spent in UNet forwards."""
+    import numpy as np
+    import torch
+    from ivid_amd.diffusion import frameworks
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    from ivid_amd.inference.sample import sample_all
+    from ivid_amd.rgbd_3d import camera
+    bs = 32 if a.batch == 64 else a.batch
+    su, sc = a.c3_steps_uncond, a.c3_steps_cond
+
+    def model(args, seed):
+        sd = C.synth_weights(args, seed) if rank == 0 else None
+        sd = parallel.broadcast_state_dict(C.schema_for(args), sd, device=dev)
+        m = AdmUnet2d(**args, precision=a.precision)
+        m.load_state_dict(sd, strict=True)
+        return m.to(dev).eval()
+    cargs = dict(C.LARGE128, in_channels=10)          # rgbd_imagenet_adm_128_large_cond.json
+    mu, mc = model(C.LARGE128, 0), model(cargs, 2)
+    fu = frameworks.ClassifierFreeGuidance(mu, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    fc = frameworks.InpaintCFG(mc, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
+    seeds = [rank * bs + i for i in range(bs)]
+    classes = [s % 1000 for s in seeds]
+    views = camera.viewset("random", bs, np.random.default_rng(rank))
+
+    def run(n_u, n_c):
+        return list(sample_all(fu, fc, seeds, n_u, n_c, views, classes=classes, guidance=3.0, batchsize=bs))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    run_short(fu, fc, seeds, views, classes, bs, sample_all)   # warm-up: plans, hipGraphs, warp buffers (no 1000-step chain)
+    fence()
+    t0 = time.perf_counter()
+    res = run(su, sc)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert len(res) == bs and all(torch.isfinite(r[0]).all() for r in res)
+    # pure UNet time of the same number of forwards: the stacked-CFG batch-2*bs hipGraph of each model, timed alone
+    def fwd_ms(m, cin):
+        x = torch.randn(bs, cin, 128, 128, device=dev)
+        t = torch.full((bs,), 500, dtype=torch.long, device=dev)
+        c = torch.tensor(classes, device=dev)
+        for _ in range(3):
+            m.forward_cfg(x, t, c)
+        torch.cuda.synchronize(dev)
+        q0 = time.perf_counter()
+        for _ in range(10):
+            m.forward_cfg(x, t, c)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - q0) * 100.0
+    mu_ms, mc_ms = fwd_ms(mu, 4), fwd_ms(mc, 10)
+    unet_s = (su * mu_ms + sc * mc_ms) / 1e3
+    out = {
+        "metric": "samples/s end to end, BASELINE config 3 (uncond + cond iterative `random` viewset)",
+        "value": round(bs * world / dt, 4), "unit": "samples/s (2 views each: 1 unconditional + 1 warped/inpainted)",
+        "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded random-init weights)",
+        "config": {"workload": "rgbd_imagenet_adm_128_large_cfg (DDPM %d steps, CFG 3.0) + rgbd_imagenet_adm_128_large_cond "
+                               "(DDIM %d steps, InpaintCFG 3.0), viewset random, bs=%d per GPU, HIP depth-warp in the loop" % (su, sc, bs),
+                   "parallelism": "sample-parallel x%d" % world},
+        "seconds_per_batch": round(dt, 3),
+        "unet_forward_ms": {"uncond_stacked_bs%d" % (2 * bs): round(mu_ms, 3), "cond_stacked_bs%d" % (2 * bs): round(mc_ms, 3)},
+        "unet_seconds_per_batch": round(unet_s, 3),
+        "share_outside_unet": round(max(0.0, 1.0 - unet_s / dt), 4),
+        "sample_fwd_per_s_end_to_end": round(2 * bs * (su + sc) * world / dt, 1),
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_short(fu, fc, seeds, views, classes, bs, sample_all):
+    """Warm-up of the c3 loop with the real sampler types (DDPM needs steps >= 1000 to be selected): two batches of the
+    unconditional DDPM are too slow to repeat, so the warm-up runs the DDPM sampler for its first steps only."""
+    from ivid_amd.diffusion import samplers
+    import torch
+    sm = samplers.DdpmSampler(fu)
+    dev = fu.backbone.device
+    x = torch.randn(bs, 4, 128, 128, device=dev)
+    cls = torch.tensor(classes, device=dev)
+    for t in (999, 998, 997):
+        x = sm.sample_once(x, t, cls, strength=3.0).pred_x_prev
+    list(sample_all(fu, fc, seeds[:bs], 2, 2, views, classes=classes, guidance=3.0, batchsize=bs))
 
 
 def cpu_baseline(C, margs, has_cls, model_name, B, unit):

@@ -43,6 +43,40 @@ int ivid_event_record(void* ev, void* stream);
 int ivid_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
 int ivid_event_destroy(void* ev);
 
+/* ---- launch program: the C-side owner of one planned UNet forward (the `ivid_unet_create / ivid_unet_forward` handle of the
+ *      boundary; replaces AdmUnet2d.forward's ~650-700 torch launches, adm.py:526-566) ----
+ * The host plans the forward once (which entry points below, in which order, on which caller-owned buffers) and appends the
+ * launches; afterwards a forward is ONE call.  `args` of ivid_program_add: one 8-byte slot per argument of the entry point,
+ * WITHOUT the trailing stream, in declaration order: integers and device pointers as int64, floats as double. */
+#define IVID_OP_CONV2D 1          /* ivid_conv2d */
+#define IVID_OP_CONV3X3_GN 2      /* ivid_conv3x3_gn */
+#define IVID_OP_CONV3X3_GN_SKIP 3 /* ivid_conv3x3_gn_skip */
+#define IVID_OP_CONV3X3_GN_OUT 4  /* ivid_conv3x3_gn_out */
+#define IVID_OP_GN_PARTIAL 5      /* ivid_gn_partial */
+#define IVID_OP_GN_FINALIZE 6     /* ivid_gn_finalize */
+#define IVID_OP_GN_FINALIZE2 7    /* ivid_gn_finalize2 */
+#define IVID_OP_GN_APPLY 8        /* ivid_gn_apply */
+#define IVID_OP_ATTENTION 9       /* ivid_attention */
+#define IVID_OP_EMBED_INPUTS 10   /* ivid_embed_inputs */
+#define IVID_OP_SILU_F32 11       /* ivid_silu_f32 */
+#define IVID_OP_STEM_IM2COL 12    /* ivid_stem_im2col */
+int ivid_program_create(void** handle_out);
+int ivid_program_add(void* handle, int op, const void* args, int nargs);
+int ivid_program_num_ops(void* handle);
+/* Replay on `stream`: use_graph = 0 always eager; else run 1 eager (sets kernel attributes), run 2 captures a hipGraph,
+ * later runs are one hipGraphLaunch (the stream must not be the legacy default stream). */
+int ivid_program_launch(void* handle, int use_graph, void* stream);
+int ivid_program_has_graph(void* handle);
+int ivid_program_destroy(void* handle);
+/* Model boundary of a UNet program: its static input buffers (x fp32 NCHW of x_bytes, times / classes int64 [batch];
+ * c_in NULL for a model without class embedding) and its output buffer (fp32 NCHW of out_bytes). */
+int ivid_unet_bind(void* handle, void* x_in, long long x_bytes, void* t_in, void* c_in, int batch, void* out,
+                   long long out_bytes);
+/* AdmUnet2d.forward(x, times, classes) (adm.py:526-566) as one call: device pointers; classes NULL = the null class for every
+ * row; out NULL = leave the result in the program's own output buffer.  Everything is enqueued on `stream`. */
+int ivid_unet_forward(void* handle, const void* x, const void* times, const void* classes, void* out, int use_graph,
+                      void* stream);
+
 /* ---- convolution / linear: nn.Conv2d 3x3 pad1 (adm.py:160,182,369,486), nn.Conv2d 1x1 skip (adm.py:190),
  *      nn.Conv1d k=1 qkv/proj_out (adm.py:275,278), nn.Linear (adm.py:176,359,361) ----
  * out[n,y,x,co] = bias[co] + sum_{tap,c} cat(src0,src1)[n,y+dy,x+dx,c] * weight[co][tap][c]  (+ residual)

@@ -44,6 +44,14 @@ SIGNATURES = {
     "ivid_event_record": (i32, [vp, vp]),
     "ivid_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
     "ivid_event_destroy": (i32, [vp]),
+    "ivid_program_create": (i32, [C.POINTER(vp)]),
+    "ivid_program_add": (i32, [vp, i32, vp, i32]),
+    "ivid_program_num_ops": (i32, [vp]),
+    "ivid_program_launch": (i32, [vp, i32, vp]),
+    "ivid_program_has_graph": (i32, [vp]),
+    "ivid_program_destroy": (i32, [vp]),
+    "ivid_unet_bind": (i32, [vp, vp, i64, vp, vp, i32, vp, i64]),
+    "ivid_unet_forward": (i32, [vp, vp, vp, vp, vp, i32, vp]),
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
     "ivid_conv3x3_gn": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -73,6 +81,30 @@ SIGNATURES = {
     "ivid_warp_resolve": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, C.c_float, C.c_float, C.c_float,
                                 C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
 }
+
+# op codes of the launch program (include/ivid_hip.h IVID_OP_*)
+OP_CODES = {"ivid_conv2d": 1, "ivid_conv3x3_gn": 2, "ivid_conv3x3_gn_skip": 3, "ivid_conv3x3_gn_out": 4, "ivid_gn_partial": 5,
+            "ivid_gn_finalize": 6, "ivid_gn_finalize2": 7, "ivid_gn_apply": 8, "ivid_attention": 9, "ivid_embed_inputs": 10,
+            "ivid_silu_f32": 11, "ivid_stem_im2col": 12}
+
+
+class Slot(C.Union):
+    _fields_ = [("i", C.c_longlong), ("f", C.c_double)]
+
+
+def pack_args(name, args):
+    """Arguments of one recorded launch (without the stream) -> the 8-byte slots ivid_program_add expects: floats (per the
+    entry point's ctypes signature) as double, everything else (ints, device pointers, None) as int64."""
+    sig = SIGNATURES[name][1][:-1]
+    assert len(sig) == len(args), (name, len(sig), len(args))
+    arr = (Slot * len(args))()
+    for k, (ty, v) in enumerate(zip(sig, args)):
+        if ty is C.c_float:
+            arr[k].f = float(v)
+        else:
+            arr[k].i = 0 if v is None else int(v)
+    return arr
+
 
 _lib = None
 

@@ -1,0 +1,172 @@
+// Launch program: the C-side owner of one UNet forward (SURVEY.md §8b "ivid_unet_create / ivid_unet_forward").
+//
+// The host plans a forward ONCE (which kernels, in which order, on which arena buffers: ivid_amd/diffusion/backbones/
+// plan.py) and hands the resulting launch list to this object; from then on a forward is ONE C call: copy the caller's
+// inputs into the program's static input buffers, replay the list (first call: eagerly, which also sets kernel
+// attributes; second call: captured into a hipGraph; afterwards: hipGraphLaunch), copy the result out.  No Python runs
+// per forward, and a non-Python host can drive the same object through include/ivid_hip.h.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "internal.h"
+
+namespace {
+
+union Slot { long long i; double f; };
+struct Op { int code; int nargs; Slot a[24]; };
+
+struct Program {
+  std::vector<Op> ops;
+  hipGraphExec_t graph = nullptr;
+  int runs = 0;
+  // model boundary (optional): static input / output buffers of the plan
+  float* x_in = nullptr; long long x_bytes = 0;
+  long long* t_in = nullptr; long long* c_in = nullptr; int batch = 0;
+  float* out = nullptr; long long out_bytes = 0;
+};
+
+#define P(k) ((void*)(intptr_t)o.a[k].i)
+#define CP(k) ((const void*)(intptr_t)o.a[k].i)
+#define FP(k) ((float*)(intptr_t)o.a[k].i)
+#define CFP(k) ((const float*)(intptr_t)o.a[k].i)
+#define I(k) ((int)o.a[k].i)
+#define F(k) ((float)o.a[k].f)
+
+int run_op(const Op& o, void* s) {
+  switch (o.code) {
+    case IVID_OP_CONV2D:
+      return ivid_conv2d(I(0), CP(1), I(2), CP(3), I(4), CP(5), CFP(6), P(7), CP(8), I(9), I(10), I(11), I(12), I(13), I(14), I(15),
+                         I(16), FP(17), s);
+    case IVID_OP_CONV3X3_GN:
+      return ivid_conv3x3_gn(I(0), CP(1), I(2), CP(3), I(4), CFP(5), I(6), CP(7), CFP(8), P(9), CP(10), I(11), I(12), I(13), I(14),
+                             I(15), FP(16), s);
+    case IVID_OP_CONV3X3_GN_SKIP:
+      return ivid_conv3x3_gn_skip(I(0), CP(1), I(2), CP(3), I(4), CFP(5), I(6), CP(7), CFP(8), P(9), CP(10), I(11), I(12), I(13),
+                                  I(14), I(15), FP(16), CP(17), I(18), CP(19), I(20), CP(21), s);
+    case IVID_OP_CONV3X3_GN_OUT:
+      return ivid_conv3x3_gn_out(I(0), CP(1), I(2), CFP(3), CP(4), CFP(5), FP(6), I(7), I(8), I(9), I(10), s);
+    case IVID_OP_GN_PARTIAL:
+      return ivid_gn_partial(I(0), CP(1), I(2), CP(3), I(4), I(5), I(6), FP(7), s);
+    case IVID_OP_GN_FINALIZE:
+      return ivid_gn_finalize(CFP(0), I(1), I(2), I(3), I(4), I(5), F(6), CFP(7), CFP(8), CFP(9), I(10), I(11), FP(12), s);
+    case IVID_OP_GN_FINALIZE2:
+      return ivid_gn_finalize2(CFP(0), I(1), I(2), CFP(3), I(4), I(5), I(6), I(7), I(8), F(9), CFP(10), CFP(11), CFP(12), I(13),
+                               I(14), FP(15), s);
+    case IVID_OP_GN_APPLY:
+      return ivid_gn_apply(I(0), CP(1), I(2), CP(3), I(4), CFP(5), P(6), I(7), I(8), I(9), I(10), I(11), s);
+    case IVID_OP_ATTENTION:
+      return ivid_attention(I(0), CP(1), P(2), I(3), I(4), I(5), s);
+    case IVID_OP_EMBED_INPUTS:
+      return ivid_embed_inputs((const int64_t*)CP(0), (const int64_t*)CP(1), I(2), I(3), I(4), CFP(5), I(6), CFP(7), I(8), FP(9),
+                               FP(10), s);
+    case IVID_OP_SILU_F32:
+      return ivid_silu_f32(CFP(0), FP(1), o.a[2].i, s);
+    case IVID_OP_STEM_IM2COL:
+      return ivid_stem_im2col(I(0), CFP(1), I(2), I(3), I(4), I(5), I(6), I(7), P(8), s);
+    default:
+      return ivid_set_error("program: unknown op code", hipSuccess);
+  }
+}
+
+}  // namespace
+
+extern "C" int ivid_program_create(void** handle_out) {
+  if (!handle_out) return ivid_set_error("program_create: null", hipSuccess);
+  *handle_out = new Program();
+  return 0;
+}
+
+// args: nargs slots of 8 bytes each; integers and device pointers as int64, floats as double (see ivid_hip.h)
+extern "C" int ivid_program_add(void* handle, int op, const void* args, int nargs) {
+  Program* p = (Program*)handle;
+  if (!p || nargs < 0 || nargs > 24 || (nargs && !args)) return ivid_set_error("program_add: bad arguments", hipSuccess);
+  if (p->graph) return ivid_set_error("program_add: program already captured", hipSuccess);
+  Op o;
+  o.code = op;
+  o.nargs = nargs;
+  memcpy(o.a, args, (size_t)nargs * sizeof(Slot));
+  p->ops.push_back(o);
+  return 0;
+}
+
+extern "C" int ivid_program_num_ops(void* handle) { return handle ? (int)((Program*)handle)->ops.size() : -1; }
+
+static int enqueue(Program* p, void* stream) {
+  for (size_t k = 0; k < p->ops.size(); ++k) {
+    const int st = run_op(p->ops[k], stream);
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+// Replay the launch list on `stream`.  use_graph = 0: always eager.  Otherwise run 1 is eager (kernel attributes, zero
+// page), run 2 captures the list into a hipGraph, later runs are one hipGraphLaunch.
+extern "C" int ivid_program_launch(void* handle, int use_graph, void* stream) {
+  Program* p = (Program*)handle;
+  if (!p) return ivid_set_error("program_launch: null handle", hipSuccess);
+  hipStream_t s = (hipStream_t)stream;
+  if (!use_graph || p->runs == 0) {
+    p->runs++;
+    return enqueue(p, stream);
+  }
+  if (!p->graph) {
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return ivid_set_error("program: hipStreamBeginCapture", e);
+    const int st = enqueue(p, stream);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s, &g);
+    if (st != 0) { if (g) hipGraphDestroy(g); return st; }
+    if (e != hipSuccess) return ivid_set_error("program: hipStreamEndCapture", e);
+    e = hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return ivid_set_error("program: hipGraphInstantiate", e);
+  }
+  p->runs++;
+  hipError_t e = hipGraphLaunch(p->graph, s);
+  return e == hipSuccess ? 0 : ivid_set_error("program: hipGraphLaunch", e);
+}
+
+extern "C" int ivid_program_has_graph(void* handle) { return handle && ((Program*)handle)->graph ? 1 : 0; }
+
+// Declare the model boundary of a UNet program: its static input buffers (x fp32 [batch,Cin,S,S] = x_bytes, times /
+// classes int64 [batch], classes NULL for models without class embedding) and its output buffer (fp32 NCHW, out_bytes).
+extern "C" int ivid_unet_bind(void* handle, void* x_in, long long x_bytes, void* t_in, void* c_in, int batch, void* out,
+                              long long out_bytes) {
+  Program* p = (Program*)handle;
+  if (!p || !x_in || !t_in || !out || batch <= 0) return ivid_set_error("unet_bind: bad arguments", hipSuccess);
+  p->x_in = (float*)x_in; p->x_bytes = x_bytes; p->t_in = (long long*)t_in; p->c_in = (long long*)c_in; p->batch = batch;
+  p->out = (float*)out; p->out_bytes = out_bytes;
+  return 0;
+}
+
+// AdmUnet2d.forward (adm.py:526-566) as ONE call: x fp32 NCHW, times int64 [batch], classes int64 [batch] or NULL (= null
+// class for every row), out fp32 NCHW (NULL: leave the result in the program's own output buffer).  All device pointers,
+// everything enqueued on `stream`, nothing synchronises.
+extern "C" int ivid_unet_forward(void* handle, const void* x, const void* times, const void* classes, void* out, int use_graph,
+                                 void* stream) {
+  Program* p = (Program*)handle;
+  if (!p || !p->x_in) return ivid_set_error("unet_forward: program has no bound boundary (ivid_unet_bind)", hipSuccess);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(p->x_in, x, (size_t)p->x_bytes, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(p->t_in, times, (size_t)p->batch * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess && p->c_in) {
+    if (classes) e = hipMemcpyAsync(p->c_in, classes, (size_t)p->batch * 8, hipMemcpyDeviceToDevice, s);
+    else e = hipMemsetAsync(p->c_in, 0xff, (size_t)p->batch * 8, s);   // int64 -1 = null class (adm.py:550-552)
+  }
+  if (e != hipSuccess) return ivid_set_error("unet_forward: input copy", e);
+  const int st = ivid_program_launch(handle, use_graph, stream);
+  if (st != 0) return st;
+  if (out && out != (void*)p->out) {
+    e = hipMemcpyAsync(out, p->out, (size_t)p->out_bytes, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return ivid_set_error("unet_forward: output copy", e);
+  }
+  return 0;
+}
+
+extern "C" int ivid_program_destroy(void* handle) {
+  Program* p = (Program*)handle;
+  if (!p) return 0;
+  if (p->graph) hipGraphExecDestroy(p->graph);
+  delete p;
+  return 0;
+}

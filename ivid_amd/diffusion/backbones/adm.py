@@ -191,7 +191,7 @@ class AdmUnet2d(nn.Module):
             f"expected input [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
         if x.shape[0] == 0:   # empty batch: what the reference's torch ops return (no launch)
             return x.new_zeros((0, self.out_channels, self.image_size, self.image_size), dtype=torch.float32)
-        out = self.plan(x.shape[0], False).run(x.float(), times, classes, self.use_graph)
+        out = self.plan(x.shape[0], False).run(x.float().contiguous(), times, classes, self.use_graph)
         return out.clone()
 
     @torch.no_grad()
@@ -202,5 +202,5 @@ class AdmUnet2d(nn.Module):
         classifier_free_guidance.py:39-42 / inpaint_cfg.py:80-83."""
         assert self.num_classes is not None and classes is not None
         b = x.shape[0]
-        out = self.plan(b, True).run(x.float(), times, classes, self.use_graph)
+        out = self.plan(b, True).run(x.float().contiguous(), times, classes, self.use_graph)
         return out[:b], out[b:]

@@ -171,6 +171,22 @@ class UNetPlan:
         # unless the caller changed it: the plan runs on its own stream, fenced against the caller's.
         self.stream = torch.cuda.Stream(device=device)
         self._build()
+        self.program = None
+        if not debug and os.environ.get("IVID_PY_LAUNCH", "0") != "1":
+            self._make_program()
+
+    def _make_program(self):
+        """Hand the planned launch list to the C-side program (csrc/program.hip): from here on a forward is ONE C call
+        (ivid_unet_forward: input copies + hipGraph replay + nothing else), no Python per launch."""
+        h = C.c_void_p()
+        _lib.call("ivid_program_create", C.byref(h))
+        for fn, name, args in self.launches:
+            arr = _lib.pack_args(name, args)
+            _lib.call("ivid_program_add", h, _lib.OP_CODES[name], C.cast(arr, C.c_void_p), len(args))
+        has_cls = self.spec.num_classes is not None
+        _lib.call("ivid_unet_bind", h, self.x_in.data_ptr(), self.x_in.numel() * 4, self.t_in.data_ptr(),
+                  self.c_in.data_ptr() if has_cls else None, self.bsrc, self.out.data_ptr(), self.out.numel() * 4)
+        self.program = h
 
     # ---- launch recording ----
     def _rec(self, name, *args):
@@ -429,6 +445,18 @@ class UNetPlan:
         """x [bsrc,Cin,S,S] fp32, times [bsrc] int64, classes [bsrc] int64 or None -> self.out (static buffer)."""
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        if self.program is not None:
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == self.x_in.shape, "x must be fp32 NCHW"
+            t64 = times.to(torch.int64).contiguous()
+            c64 = classes.to(torch.int64).contiguous() if (classes is not None and self.spec.num_classes is not None) else None
+            with torch.cuda.stream(self.stream):
+                _lib.call("ivid_unet_forward", self.program, x.data_ptr(), t64.data_ptr(), c64.data_ptr() if c64 is not None else None,
+                          None, 1 if use_graph else 0, C.c_void_p(self.stream.cuda_stream))
+                for tns in (x, t64, c64):            # their memory must outlive the copies enqueued on the plan's stream
+                    if tns is not None:
+                        tns.record_stream(self.stream)
+            cur.wait_stream(self.stream)
+            return self.out
         with torch.cuda.stream(self.stream):
             self.x_in.copy_(x)
             self.t_in.copy_(times)
@@ -444,6 +472,9 @@ class UNetPlan:
     def launch(self, use_graph=True):
         """Enqueue one forward on self.stream from the static input buffers (no host sync)."""
         stream = self.stream.cuda_stream
+        if self.program is not None:
+            _lib.call("ivid_program_launch", self.program, 1 if use_graph else 0, C.c_void_p(stream))
+            return
         if self.debug or not use_graph or not self.warm:
             self._enqueue(stream)   # first run is eager: sets kernel attributes, creates the zero page
             self.warm = True
@@ -486,9 +517,17 @@ class UNetPlan:
             _lib.call("ivid_event_destroy", e1)
         return out
 
+    @property
+    def has_graph(self):
+        if self.program is not None:
+            return bool(self.lib.ivid_program_has_graph(self.program))
+        return self.graph is not None
+
     def __del__(self):
         try:
             if self.graph is not None:
                 self.lib.ivid_graph_destroy(self.graph)
+            if getattr(self, "program", None) is not None:
+                self.lib.ivid_program_destroy(self.program)
         except Exception:
             pass

@@ -205,3 +205,24 @@ def test_cfg_branches_follow_the_reference_for_every_sign_of_strength():
         assert torch.allclose(out, torch.full((2, 1), want)) and len(calls) == ncalls, s
     calls.clear()
     assert torch.allclose(cfg_combine(*cfg_branches(backbone, x, t, None, 3.0)), torch.full((2, 1), 3.0)) and calls == [False]
+
+
+def test_launch_program_object_records_ops_without_a_gpu():
+    """csrc/program.hip: the C-side owner of a planned forward.  Creating, filling and destroying it needs no device; the
+    slot packing follows each entry point's signature (floats as double, everything else as int64)."""
+    import ctypes as CT
+    from ivid_amd import _lib
+    lib = _lib.load()
+    h = CT.c_void_p()
+    _lib.call("ivid_program_create", CT.byref(h))
+    args = (0x1000, 8, 2, 0x2000, 4, 8, 2, 256, 32, 1e-5, 0x3000, 0x4000, None, 0, 0, 0x5000)    # ivid_gn_finalize2
+    arr = _lib.pack_args("ivid_gn_finalize2", args)
+    assert arr[9].f == pytest.approx(1e-5) and arr[0].i == 0x1000 and arr[12].i == 0
+    _lib.call("ivid_program_add", h, _lib.OP_CODES["ivid_gn_finalize2"], CT.cast(arr, CT.c_void_p), len(args))
+    assert lib.ivid_program_num_ops(h) == 1 and lib.ivid_program_has_graph(h) == 0
+    with pytest.raises(_lib.IvidHipError):
+        _lib.call("ivid_unet_forward", h, None, None, None, None, 1, None)       # no boundary bound yet
+    _lib.call("ivid_program_destroy", h)
+    hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
+    for name, code in _lib.OP_CODES.items():
+        assert re.search(rf"#define IVID_OP_{name[5:].upper()} {code}\b", hdr), name

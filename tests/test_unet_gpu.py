@@ -74,7 +74,7 @@ def test_mini_forward_graph_replay_is_bit_identical_to_eager():
     a = m(xs, ts, cs)          # eager (first call)
     b = m(xs, ts, cs)          # captures + replays
     c = m(xs, ts, cs)          # replay
-    assert m.plan(2, False).graph is not None
+    assert m.plan(2, False).has_graph
     assert torch.equal(a, b) and torch.equal(b, c)
     # new inputs flow through the static buffers of the captured graph
     x2 = C.seeded_randn(999, 2, 4, 32, 32)
