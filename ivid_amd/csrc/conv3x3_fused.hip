@@ -659,7 +659,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             st_s[e] += sv[e];
-            st_q[e] += sv[e] * sv[e];
+            st_q[e] = __builtin_fmaf(sv[e], sv[e], st_q[e]);
           }
         }
       }

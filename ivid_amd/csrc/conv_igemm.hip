@@ -238,7 +238,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   constexpr int LDC = WTN + 4;  // floats per slab row (pad keeps the two half-waves on different banks)
   float* slab = (float*)smem + wave * (32 * LDC);
   const int Cout = p.Cout;
-  float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's WTM pixels (fused gn_partial)
+  // GroupNorm partial statistics of this wave's pixels (fused gn_partial).  The fp32 summation ORDER of a 64-pixel block must
+  // not depend on the tile a launch happens to use (the choice depends on the batch size, and a sample's result has to
+  // be bit-identical in any batch / on any rank): canonical order = the one of the 64-channel-wide wave tiles -- rows of
+  // equal (row mod VE) are summed sequentially in increasing row order, the VE partial sums are combined by a binary
+  // tree over the bits of (row mod VE), lowest bit first.  A 128-wide wave tile covers fewer rows per pass (RPP = VE/2):
+  // it keeps NA = 2 accumulators per lane (row mod VE = lr and lr + RPP), runs the tree over the lane bits first and
+  // adds the two accumulators last -- the same association.
+  constexpr int NA = WTN > 64 ? WTN / 64 : 1;
+  float st_s[NA][VE], st_q[NA][VE];
   float bv[VE];              // this lane's bias values (NHWC path): the same 16-byte channel piece in every pass
   {
     const int nb = n0 + wn * WTN + (lane % (WTN / VE)) * VE;
@@ -287,7 +295,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       constexpr int FL = MI >= 2 ? 2 : 1;  // fragments per statistics block
       if (mi % FL == 0) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) st_s[j][e] = st_q[j][e] = 0.f;
       }
 #pragma unroll
       for (int ps = 0; ps < 32 / RPP; ++ps) {
@@ -341,8 +351,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
             vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-              st_s[e] += sv[e];
-              st_q[e] += sv[e] * sv[e];
+              st_s[ps % NA][e] += sv[e];
+              st_q[ps % NA][e] = __builtin_fmaf(sv[e], sv[e], st_q[ps % NA][e]);   // explicit: contraction must not vary per instantiation
             }
           }
         }
@@ -352,8 +362,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
-            st_s[e] += __shfl_xor(st_s[e], off);
-            st_q[e] += __shfl_xor(st_q[e], off);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              st_s[j][e] += __shfl_xor(st_s[j][e], off);
+              st_q[j][e] += __shfl_xor(st_q[j][e], off);
+            }
           }
         }
         const int n = nbase + lc;
@@ -361,7 +374,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         if (lr == 0 && wbase < p.M && n < Cout) {
           float* sp = p.stats + ((size_t)(wbase / (FL * 32)) * Cout + n) * 2;
 #pragma unroll
-          for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
+          for (int e = 0; e < VE; ++e)
+#pragma unroll
+            for (int j = 1; j < NA; ++j) { st_s[0][e] += st_s[j][e]; st_q[0][e] += st_q[j][e]; }
+#pragma unroll
+          for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[0][e], st_q[0][e], st_s[0][e + 1], st_q[0][e + 1]};
         }
       }
     } else {  // fp32 NCHW output (small Cout): lanes run along pixels for coalescing
@@ -411,7 +428,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 //   4: 512 x 128, 8 waves 8x1, wave  64 x 128 (6 reads / 8 MFMA)   Cout <= 128 (the small / SR models' first levels): the same
 //                                                                   read:MFMA ratio as tile 2 instead of tile 1's 4 / 4
 //   1: 128 x 128, 4 waves 2x2, wave  64 x 64  (4 reads / 4 MFMA)   everything else; two workgroups per CU
-//   5: 128 x 64,  4 waves 2x2, wave  64 x 32  (3 reads / 2 MFMA)   tiny problems (8^2 levels at small batch): twice the
+//   5:  64 x 128, 2 waves 1x2, wave  64 x 64  (4 reads / 4 MFMA)   tiny problems (8^2 levels at small batch): twice the
 //                                                                   workgroups of tile 1 when that one leaves CUs idle
 //   3: 128 x 32,  4 waves 4x1                                       Cout <= 32 (the 4-channel output conv)
 static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg) {
@@ -458,7 +475,7 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
     if (tile_cfg == 2) return launch_conv<TT, 256, 256, 2, 4>(a, s);       \
     if (tile_cfg == 3) return launch_conv<TT, 128, 32, 4, 1>(a, s);        \
     if (tile_cfg == 4) return launch_conv<TT, 512, 128, 8, 1>(a, s);       \
-    if (tile_cfg == 5) return launch_conv<TT, 128, 64, 2, 2>(a, s);        \
+    if (tile_cfg == 5) return launch_conv<TT, 64, 128, 1, 2>(a, s);        \
     return launch_conv<TT, 128, 128, 2, 2>(a, s);                          \
   } while (0)
   if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);
