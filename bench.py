@@ -133,11 +133,13 @@ def attn_bytes(args):
 
 
 def cached_pmc_traffic():
+    """HBM bytes per launch and kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this very
+    command, scripts/gpu_pmc_bench.sh -> profiles/pmc_traffic.json); {} when absent.  NOT measured in the current run."""
     f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return round(float(json.load(open(f))["conv_family_hbm_bytes_per_launch"]), 0)
+        return {k: round(float(v), 0) for k, v in json.load(open(f))["per_kernel_hbm_bytes_per_launch"].items()}
     except Exception:
-        return None
+        return {}
 
 
 KERNEL_OF = {"ivid_conv3x3_gn": "conv3x3_fused_kernel", "ivid_conv3x3_gn_skip": "conv3x3_fused_kernel",
@@ -345,9 +347,11 @@ def main():
         dom = dict(entries[0])
         # HBM bytes per launch of the convolution kernels from the PMC passes of this command are NOT collected in this
         # run (rocprofv3 --pmc is a separate invocation: scripts/gpu_pmc_bench.sh -> profiles/pmc_traffic.json)
-        ct = cached_pmc_traffic()
-        if ct is not None and a.precision == "bf16" and a.model == "large":
-            dom["traffic_cached"] = {"value": ct, "from": "profiles/pmc_traffic.json (conv kernels, bytes per launch, earlier run)"}
+        ct = cached_pmc_traffic() if (a.precision == "bf16" and a.model == "large" and B == 64) else {}
+        for e in entries:
+            if e["kernel"] in ct:
+                e["traffic_cached"] = {"value": ct[e["kernel"]], "from": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command)"}
+        dom = dict(entries[0])
         # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
         # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
         # profiles/r01_mfma_power.txt) -- the ceiling this kernel actually works under:

@@ -13,7 +13,6 @@
 //          applied to the V^T fragment, so no cross-lane movement of P is needed.)
 // bf16 mode: v_mfma_f32_32x32x16_bf16; V is transposed into LDS as Vt[d][kv] while staging.
 // fp32 mode: v_mfma_f32_32x32x2_f32 (exact); V stays [kv][d] (one float per lane per MFMA).
-#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 
@@ -229,17 +228,6 @@ extern "C" int ivid_attention(int dtype, const void* qkv, void* out, int N, int 
 #define LAUNCH(TT, NW) \
   hipLaunchKernelGGL((attn_kernel<TT, NW>), grid, dim3(NW * 64), 0, s, (const char*)qkv, (char*)out, T, heads)
   if (dtype == IVID_BF16) {
-#ifdef IVID_DEV_ABLATE
-    static const int wpe = getenv("IVID_ATTN_WPE") ? atoi(getenv("IVID_ATTN_WPE")) : 2;
-    if (four && wpe == 4) {
-      hipLaunchKernelGGL((attn_kernel<__bf16, 4, 4>), grid, dim3(256), 0, s, (const char*)qkv, (char*)out, T, heads);
-      return ivid_check_launch("attention");
-    }
-    if (four && wpe == 3) {
-      hipLaunchKernelGGL((attn_kernel<__bf16, 4, 3>), grid, dim3(256), 0, s, (const char*)qkv, (char*)out, T, heads);
-      return ivid_check_launch("attention");
-    }
-#endif
     if (four) LAUNCH(__bf16, 4); else LAUNCH(__bf16, 2);
   } else if (dtype == IVID_F16) {
     if (four) LAUNCH(_Float16, 4); else LAUNCH(_Float16, 2);

@@ -90,14 +90,22 @@ __global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int C0,
-                                                         const float* __restrict__ partial1, int nchunks,
-                                                         int nchunks1, int C,
-                                                         int HW, int groups, float eps,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta,
-                                                         const float* __restrict__ film, int film_stride,
-                                                         int film_off, float* __restrict__ ab) {
+constexpr int FIN_NT = 256;
+
+// One block per (image, group).  The partial sums of a group are a [nchunks][cpg] matrix per source tensor (row = 8*cpg
+// contiguous bytes inside a [nchunks][C][2] array): thread t takes channel t % cpg of chunks t / cpg, t / cpg + 256/cpg, ...
+// so that a wave reads whole rows, and the 4..16 independent loads per thread overlap (the 64-thread version of round 1
+// walked up to 16 strided loads per thread back to back: 9 us per launch, 87 launches per forward).  fp64 accumulation;
+// the cross-thread reduction is a fixed tree (shuffles, then one LDS pass over the 4 waves): deterministic.
+__global__ __launch_bounds__(FIN_NT) void gn_finalize_kernel(const float* __restrict__ partial, int C0,
+                                                             const float* __restrict__ partial1, int nchunks,
+                                                             int nchunks1, int C,
+                                                             int HW, int groups, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ film, int film_stride,
+                                                             int film_off, float* __restrict__ ab) {
+  __shared__ double red[2][FIN_NT / 64];
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int cpg = C / groups;
   const int C1 = C - C0;
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   const float* pp1 = partial1 ? partial1 + (size_t)n * nchunks1 * C1 * 2 : nullptr;
   const int nmax = nchunks > nchunks1 ? nchunks : nchunks1;
   double s = 0.0, ss = 0.0;
-  for (int idx = t; idx < nmax * cpg; idx += 64) {
+  for (int idx = t; idx < nmax * cpg; idx += FIN_NT) {
     const int ch = idx / cpg, c = g * cpg + (idx - ch * cpg);
     const float* q;
     if (c < C0) {
@@ -116,21 +124,27 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
       if (ch >= nchunks1) continue;
       q = pp1 + ((size_t)ch * C1 + (c - C0)) * 2;
     }
-    s += (double)q[0];
-    ss += (double)q[1];
+    const f32x2 v = *(const f32x2*)q;
+    s += (double)v[0];
+    ss += (double)v[1];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s += __shfl_xor(s, off);
     ss += __shfl_xor(ss, off);
   }
+  if ((t & 63) == 0) { red[0][t >> 6] = s; red[1][t >> 6] = ss; }
+  __syncthreads();
+  s = red[0][0]; ss = red[1][0];
+#pragma unroll
+  for (int w = 1; w < FIN_NT / 64; ++w) { s += red[0][w]; ss += red[1][w]; }
   const double cnt = (double)cpg * (double)HW;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
-  for (int j = t; j < cpg; j += 64) {
+  for (int j = t; j < cpg; j += FIN_NT) {
     const int c = g * cpg + j;
     float a = rstd * gamma[c];
     float b = beta[c] - meanf * a;
@@ -253,7 +267,7 @@ extern "C" int ivid_gn_finalize(const float* partial, int nchunks, int N, int C,
                                 const float* gamma, const float* beta, const float* film, int film_stride,
                                 int film_off, float* ab, void* stream) {
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize: C must be divisible by groups", hipSuccess);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial, C, nullptr, nchunks,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(FIN_NT), 0, (hipStream_t)stream, partial, C, nullptr, nchunks,
                      0, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize");
 }
@@ -265,7 +279,7 @@ extern "C" int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, co
   const int C = C0 + C1;
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize2: C must be divisible by groups", hipSuccess);
   if (C1 > 0 && !partial1) return ivid_set_error("gn_finalize2: partial1 missing", hipSuccess);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks0,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(FIN_NT), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks0,
                      nchunks1, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize2");
 }

@@ -148,6 +148,7 @@ class UNetPlan:
         self.fuse_conv = os.environ.get("IVID_NO_FUSED_CONV", "0") != "1"     # GN-apply+SiLU inside the 3x3 conv (W >= 32)
         self.fuse_skip = os.environ.get("IVID_NO_FUSED_SKIP", "0") != "1"     # 1x1 skip_connection inside that kernel too
         self._sum_bias = {}
+        self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
         self.taps = {}
         self.dtype = weights.dtype
         self.esz = _lib.esz(self.dtype)
@@ -222,9 +223,12 @@ class UNetPlan:
         if out_act is not None and out_act.stats is not None:
             stats = out_act.stats
             out_act.stats_blk = self.lib.ivid_conv2d_stats_block(n, h, w, cout, self.tile_cfg)
+        tile = self.tile_cfg
+        if tile == 0 and taps == 1 and self._tile_1x1:
+            tile = self._tile_1x1          # tuning hook (IVID_TILE_1X1): tile of the pointwise convolutions
         self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
                   self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
-                  self.tile_cfg, stats.data_ptr() if stats is not None else None)
+                  tile, stats.data_ptr() if stats is not None else None)
 
     def _linear(self, x, k, wname, out, cout, res=None):
         self._conv(_lib.F32, x.data_ptr(), k, None, 0, wname, out.data_ptr(), res.data_ptr() if res is not None else None,

@@ -35,4 +35,9 @@ if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     out["conv_family_fetch_bytes_per_launch"] = fetch / nd
     out["conv_family_write_bytes_per_launch"] = write / nd
     out["dispatches"] = nd
+    # per kernel: HBM bytes per launch (same correction), what bench.py attaches to each roofline entry as traffic_cached
+    out["per_kernel_hbm_bytes_per_launch"] = {
+        k + "_kernel": (2 * per["FETCH_SIZE"]["sum_kib"][k] / per["FETCH_SIZE"]["dispatches"][k]
+                        + per["WRITE_SIZE"]["sum_kib"].get(k, 0.0) / max(1, per["WRITE_SIZE"]["dispatches"].get(k, 1))) * 1024
+        for k in per["FETCH_SIZE"]["sum_kib"]}
 print(json.dumps(out, indent=1))
