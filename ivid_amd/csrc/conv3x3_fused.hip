@@ -707,7 +707,11 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
-  if (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke) return ivid_set_error("conv3x3_gn: channels must be multiples of the K-step", hipSuccess);
+  // Cout <= 128 (the small / SR models' first levels): the 16x32x128 variant with 64-byte chunks (csrc/conv3x3_fused128.hip)
+  static const bool no128 = getenv("IVID_NO_FUSED128") && atoi(getenv("IVID_NO_FUSED128"));
+  const bool narrow = !no128 && skipC0 == 0 && C1 >= 0 && ivid_fused128_supports(dtype, C0, C1, H, W, Cout);
+  if (!narrow && (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke))
+    return ivid_set_error("conv3x3_gn: channels must be multiples of the K-step", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("conv3x3_gn: src1 missing", hipSuccess);
   if (W % TW || H % TH) return ivid_set_error("conv3x3_gn: needs W % 32 == 0 and H % 8 == 0 (use ivid_gn_apply + ivid_conv2d otherwise)", hipSuccess);
   if (Cout % ve) return ivid_set_error("conv3x3_gn: Cout must be a multiple of 16 bytes", hipSuccess);
@@ -724,6 +728,8 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
         (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
+  if (narrow)
+    return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, stream);
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;

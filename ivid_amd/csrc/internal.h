@@ -11,3 +11,9 @@ const void* ivid_zero_page();                        // 256 zero bytes in device
 static inline int ivid_esz(int dtype) {
   return (dtype == IVID_F32 || dtype == IVID_BF16X3) ? 4 : ((dtype == IVID_BF16 || dtype == IVID_F16) ? 2 : 0);
 }
+
+// csrc/conv3x3_fused128.hip: the Cout <= 128 variant of the fused GroupNorm-apply + SiLU + conv3x3 kernel
+bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout);
+int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                         const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
+                         int Cout, float* stats, void* stream);

@@ -147,6 +147,7 @@ class UNetPlan:
         self.fuse_stats = os.environ.get("IVID_NO_FUSED_STATS", "0") != "1"   # GN partials from conv epilogues
         self.fuse_conv = os.environ.get("IVID_NO_FUSED_CONV", "0") != "1"     # GN-apply+SiLU inside the 3x3 conv (W >= 32)
         self.fuse_skip = os.environ.get("IVID_NO_FUSED_SKIP", "0") != "1"     # 1x1 skip_connection inside that kernel too
+        self.fuse_narrow = os.environ.get("IVID_NO_FUSED128", "0") != "1"     # Cout <= 128 through the 16x32x128 variant
         self._sum_bias = {}
         self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
         self.taps = {}
@@ -296,9 +297,10 @@ class UNetPlan:
         n = x.n
         resample = {"same": 0, "up": 1, "down": 2}[op.mode]
         so = op.res_out
-        # the fused kernel's tile is 256 output channels wide: at Cout <= 128 (the small / SR models' first levels) half of
-        # its MFMAs would be padding and gn_apply + the 128x128-tile igemm is faster (measured 1.29 vs 0.86 + 0.2 ms)
-        fused2 = self.fuse_conv and so % 32 == 0 and op.cout > 128      # out_layers conv: its input is at the output size
+        # Cout > 128: the 8x32x256 fused kernel.  Cout <= 128 (the small / SR models' first levels): its 16x32x128 variant
+        # with 64-byte chunks (csrc/conv3x3_fused128.hip; not for bf16x3, which keeps gn_apply + igemm there)
+        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and so % 32 == 0
+        fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         h1 = self._new(n, so, op.cout, stats=True)
         if fused:
@@ -317,7 +319,7 @@ class UNetPlan:
             self._free(h1)
         out = self._new(n, so, op.cout, stats=True)
         kstep = 128 // self.esz
-        if (fused2 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
+        if (fused2 and op.cout > 128 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
                 and (skip is None or skip.c % kstep == 0)):
             # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
             # residual round trip)

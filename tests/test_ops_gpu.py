@@ -144,6 +144,17 @@ FUSED_CASES = [
     ("wide_2ntiles", 1, 16, 64, 64, 0, 512, 0, 1),
     ("tall_cout320", 1, 40, 32, 128, 0, 320, 0, 0),
     ("down_res_avgpool", 2, 16, 32, 64, 0, 96, 0, 3),
+    # the 8x32x256 kernel proper (Cout > 128, or H % 16 != 0)
+    ("wide_same_res_c192", 2, 32, 32, 64, 0, 192, 0, 1),
+    ("wide_up_res_up_c256", 2, 32, 32, 64, 0, 256, 1, 2),
+    ("wide_down_avgpool_c160", 2, 16, 32, 64, 0, 160, 0, 3),
+    ("wide_h8_concat_c64", 2, 8, 64, 64, 64, 64, 0, 1),
+    # Cout <= 128 and H % 16 == 0: the 16x32x128 variant (csrc/conv3x3_fused128.hip)
+    ("n128_same_c128", 2, 32, 32, 128, 0, 128, 0, 0),
+    ("n128_concat_res_c96tail", 2, 32, 64, 128, 64, 96, 0, 1),
+    ("n128_up_res_up", 2, 32, 32, 64, 0, 128, 1, 2),
+    ("n128_down_res_avgpool_c32in", 3, 16, 32, 32, 0, 64, 0, 3),
+    ("n128_tall_3tiles", 1, 48, 32, 160, 0, 128, 0, 1),
 ]
 
 
