@@ -709,7 +709,7 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   const int bke = 128 / esz, ve = 16 / esz;
   // Cout <= 128 (the small / SR models' first levels): the 16x32x128 variant with 64-byte chunks (csrc/conv3x3_fused128.hip)
   static const bool no128 = getenv("IVID_NO_FUSED128") && atoi(getenv("IVID_NO_FUSED128"));
-  const bool narrow = !no128 && skipC0 == 0 && C1 >= 0 && ivid_fused128_supports(dtype, C0, C1, H, W, Cout);
+  const bool narrow = !no128 && ivid_fused128_supports(dtype, C0, C1, H, W, Cout, skipC0, skipC1);
   if (!narrow && (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke))
     return ivid_set_error("conv3x3_gn: channels must be multiples of the K-step", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("conv3x3_gn: src1 missing", hipSuccess);
@@ -718,7 +718,8 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   if (up && ((H | W) & 1)) return ivid_set_error("conv3x3_gn: upsample needs even H,W", hipSuccess);
   if (res_mode < 0 || res_mode > 3 || (res_mode && !res)) return ivid_set_error("conv3x3_gn: bad residual", hipSuccess);
   if (!ab) return ivid_set_error("conv3x3_gn: ab missing", hipSuccess);
-  if (skipC0 < 0 || skipC1 < 0 || skipC0 % bke || skipC1 % bke || (skipC0 == 0 && skipC1 > 0))
+  const int sbke = narrow ? bke / 2 : bke;   // the 128-wide variant works on 64-byte chunks
+  if (skipC0 < 0 || skipC1 < 0 || skipC0 % sbke || skipC1 % sbke || (skipC0 == 0 && skipC1 > 0))
     return ivid_set_error("conv3x3_gn: skip channels must be multiples of the K-step", hipSuccess);
   if (skipC0 > 0 && (!skip0 || !skip_weight || (skipC1 > 0 && !skip1)))
     return ivid_set_error("conv3x3_gn: skip source / weight missing", hipSuccess);
@@ -729,7 +730,8 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
   if (narrow)
-    return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, stream);
+    return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, skip0,
+                                skipC0, skip1, skipC1, skip_weight, stream);
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;

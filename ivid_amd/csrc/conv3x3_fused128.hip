@@ -12,7 +12,8 @@
 //               48,960 B per image -- the same LDS budget as the wide kernel's 340 x 144; weights [128][64 B] per (chunk, tap)
 //   K-step    : (chunk, tap) = 2 MFMA k-blocks, 16 MFMAs per wave; 5 halo pieces per thread and chunk (pipeline distance 2)
 //   LDS       : 2 x 48,960 + 2 x 8,192 = 114,304 B
-// 16-bit and fp32 storage types; the split-bf16 mode and the folded 1x1 skip phase stay with the other kernels.
+//   optional  : the ResBlock's 1x1 skip_connection accumulated into the same tile after the 3x3 K-steps (as in the wide kernel)
+// 16-bit and fp32 storage types; the split-bf16 mode stays with gn_apply + conv_igemm.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -352,6 +353,68 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
   chunk_body(chunks - 1, std::false_type{});
   if (grp == 0) __syncthreads();  // the two wave groups are aligned again
 
+  // ---------------- optional skip phase: acc += x[tile pixels] . Wskip  (the ResBlock's 1x1 skip_connection on its raw
+  // input x = cat(sk0, sk1), adm.py:190,222): a plain 2-stage LDS-DMA pipeline with taps = 1.  A stage = the tile's 512
+  // pixels x 64 B inside the now idle halo region (piece index XOR-swizzled by (row>>2)&3 like the weights), B stage as before ----
+  if (p.skC0 > 0) {
+    constexpr int SA_BYTES = TH * TW * CHB;                     // 32,768 per stage
+    static_assert(2 * SA_BYTES <= 2 * A_BYTES, "skip stages live in the halo region");
+    const int sk_ctot = p.skC0 + p.skC1;
+    const int sk_chunks = sk_ctot / BKE;
+    const int r0 = tid >> 2;                                    // stage row of piece i: 128 i + r0 (same swizzle for all i)
+    const int swz = ((tid & 3) ^ ((r0 >> 2) & 3)) << 4;
+    const size_t sk_px = (size_t)img * p.H * p.W;
+    const char* const sk0_img = p.sk0 + sk_px * p.skC0 * sizeof(T);
+    const char* const sk1_img = p.sk1 + sk_px * p.skC1 * sizeof(T);
+    int spix[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 128 * i + r0;                             // tile pixel: image row y0 + row/32, column x0 + row%32
+      spix[i] = (y0 + (row >> 5)) * p.W + x0 + (row & 31);
+    }
+    const unsigned sb_voff = (unsigned)((size_t)min(n0 + r0, p.Cout - 1) * sk_ctot * sizeof(T)) + swz;
+    auto issue_skip = [&](int stage, int c) {
+      const int cbase = c * BKE;
+      const bool second = cbase >= p.skC0;
+      const char* abase = second ? sk1_img + (size_t)(cbase - p.skC0) * sizeof(T) : sk0_img + (size_t)cbase * sizeof(T);
+      const int cb = (second ? p.skC1 : p.skC0) * (int)sizeof(T);
+      const char* wbase = p.skw + (size_t)cbase * sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        glds16_s(abase, __umul24(spix[i], cb) + swz, sA0 + stage * SA_BYTES + (i * NT + wave * 64) * 16);
+      glds16_s(wbase, sb_voff, sB0 + stage * B_BYTES + wave * 64 * 16);
+    };
+    const int sa_row = wm * 128 + frow;                          // fragment mi adds 32 rows = 2048 B (same swizzle)
+    const int sa_addr0 = sa_row * CHB + ((fhalf ^ ((sa_row >> 2) & 3)) << 4);
+    issue_skip(0, 0);
+    for (int c = 0; c < sk_chunks; ++c) {
+      wait_vmcnt0();
+      __syncthreads();  // stage c&1 landed for every wave; everyone finished reading the other stage
+      if (c + 1 < sk_chunks) issue_skip((c + 1) & 1, c + 1);
+      const int a_off = (c & 1) * SA_BYTES + sa_addr0;
+      const int b_off = (c & 1) * B_BYTES + b_addr0;
+      vec_t a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(sA0 + a_off + mi * (32 * CHB));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * (32 * CHB));
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int xo = (kk + 1) << 5;
+        const bool pf = kk < KK - 1;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) MmaT<T>::run(a[mi], b[0], acc[mi][0]);
+        if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          MmaT<T>::run(a[mi], b[1], acc[mi][1]);
+          if (pf) a[mi] = *(const vec_t*)(sA0 + (a_off ^ xo) + mi * (32 * CHB));
+        }
+        if (pf) b[1] = *(const vec_t*)(sB0 + (b_off ^ xo) + 32 * CHB);
+      }
+    }
+  }
+
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
   constexpr int LDC = WTN + 4;
   constexpr int LPR = WTN / VE, RPP = 64 / LPR, NPS = 32 / RPP;   // lanes per slab row, rows per pass, passes per fragment
@@ -494,18 +557,20 @@ template <typename T> int launch_fused128(const FusedArgs& a, hipStream_t stream
 
 }  // namespace
 
-// Can this kernel take the layer?  (Cout <= 128, 16 x 32 pixel tiles, 64-byte channel chunks, no folded skip conv, not bf16x3)
-bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout) {
+// Can this kernel take the layer?  (Cout <= 128, 16 x 32 pixel tiles, 64-byte channel chunks, not bf16x3)
+bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout, int skipC0, int skipC1) {
   const int esz = ivid_esz(dtype);
   if (!esz || dtype == IVID_BF16X3) return false;
   const int bke = CHB / esz;
-  return Cout <= BN && H % TH == 0 && W % TW == 0 && C0 > 0 && C0 % bke == 0 && C1 % bke == 0;
+  return Cout <= BN && H % TH == 0 && W % TW == 0 && C0 > 0 && C0 % bke == 0 && C1 >= 0 && C1 % bke == 0 &&
+         skipC0 >= 0 && skipC0 % bke == 0 && skipC1 >= 0 && skipC1 % bke == 0;
 }
 
 // Arguments already validated by ivid_conv3x3_gn_skip (csrc/conv3x3_fused.hip), which dispatches here.
 int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                          const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
-                         int Cout, float* stats, void* stream) {
+                         int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
+                         const void* skip_weight, void* stream) {
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;
@@ -513,7 +578,7 @@ int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, 
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.up = up ? 1 : 0; a.res_mode = res_mode;
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
-  a.sk0 = nullptr; a.sk1 = nullptr; a.skw = nullptr; a.skC0 = 0; a.skC1 = 0;
+  a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
   if (dtype == IVID_BF16) return launch_fused128<__bf16>(a, (hipStream_t)stream);
   if (dtype == IVID_F16) return launch_fused128<_Float16>(a, (hipStream_t)stream);
   return launch_fused128<float>(a, (hipStream_t)stream);

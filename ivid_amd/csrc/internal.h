@@ -13,7 +13,8 @@ static inline int ivid_esz(int dtype) {
 }
 
 // csrc/conv3x3_fused128.hip: the Cout <= 128 variant of the fused GroupNorm-apply + SiLU + conv3x3 kernel
-bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout);
+bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout, int skipC0, int skipC1);
 int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                          const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
-                         int Cout, float* stats, void* stream);
+                         int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
+                         const void* skip_weight, void* stream);

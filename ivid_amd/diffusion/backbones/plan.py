@@ -319,7 +319,9 @@ class UNetPlan:
             self._free(h1)
         out = self._new(n, so, op.cout, stats=True)
         kstep = 128 // self.esz
-        if (fused2 and op.cout > 128 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
+        if op.cout <= 128:
+            kstep //= 2                                       # the 128-wide variant works on 64-byte chunks
+        if (fused2 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
                 and (skip is None or skip.c % kstep == 0)):
             # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
             # residual round trip)

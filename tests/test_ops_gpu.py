@@ -221,6 +221,9 @@ SKIP_CASES = [
     ("skip_cat_128+64_to_64", 2, 16, 32, 64, 64, 128, 64),
     ("skip_single_256_to_320_ntiles2", 1, 8, 64, 128, 320, 256, 0),
     ("skip_cat_64+192_cout_tail_72", 1, 8, 32, 64, 72, 64, 192),
+    # Cout <= 128 and H % 16 == 0: the skip phase of the 16x32x128 variant
+    ("n128_skip_cat_128+128_to_128", 2, 32, 32, 128, 128, 128, 128),
+    ("n128_skip_single_96_to_64_h48", 1, 48, 64, 64, 64, 96, 0),
 ]
 
 
@@ -362,6 +365,41 @@ def test_conv3x3_gn_is_bitwise_repeatable_at_full_occupancy():
         assert torch.equal(o, o0) and torch.equal(st, s0)
     o1, s1 = run(1)          # 16 tiles: the first image alone
     assert torch.equal(o1[0], o0[0]) and torch.equal(s1, s0[: s1.shape[0]])
+
+
+def test_conv3x3_gn_narrow_is_bitwise_repeatable_at_full_occupancy():
+    """The same race screen for the 16x32x128 variant (csrc/conv3x3_fused128.hip: its own piece / weight-DMA mappings and
+    pipeline distances): several rounds of workgroups on every CU, repeated launches bit-identical, and identical to a
+    tiny-grid launch of the same pixels."""
+    L = G.lib()
+    N, H, W, C0, C1, Cout = 80, 64, 64, 128, 32, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    x0, x1 = rnd(N, H, W, C0).bfloat16(), rnd(N, H, W, C1).bfloat16()
+    ab = torch.stack([0.5 + torch.rand(N, C0 + C1, device="cuda", generator=g), 0.3 * rnd(N, C0 + C1)], -1).contiguous()
+    w = (rnd(Cout, 9 * (C0 + C1)) / 38).bfloat16()
+    bias = rnd(Cout) * 0.1
+    res = rnd(N, H, W, Cout).bfloat16()
+
+    def run(n):
+        out = torch.full((n, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        st = torch.full((n * H * W // 128, Cout, 2), float("nan"), device="cuda")
+        L.call("ivid_conv3x3_gn", 1, L.ptr(x0), C0, L.ptr(x1), C1, L.ptr(ab), 0, L.ptr(w), L.ptr(bias), L.ptr(out), L.ptr(res), 1,
+               n, H, W, Cout, L.ptr(st), G.stream())
+        torch.cuda.synchronize()
+        return out, st
+    o0, s0 = run(N)          # 80 * 8 = 640 tiles on 256 CUs
+    assert torch.isfinite(o0.float()).all() and torch.isfinite(s0).all()
+    for _ in range(3):
+        o, st = run(N)
+        assert torch.equal(o, o0) and torch.equal(st, s0)
+    o1, s1 = run(1)
+    assert torch.equal(o1[0], o0[0]) and torch.equal(s1, s0[: s1.shape[0]])
+    # and against the unfused composition
+    act = F.silu(torch.cat([x0, x1], -1).float() * ab[:, None, None, :, 0] + ab[:, None, None, :, 1]).bfloat16().float()
+    ref = F.conv2d(act[:2].permute(0, 3, 1, 2).double(), w.float().reshape(Cout, 9, C0 + C1).permute(0, 2, 1).reshape(Cout, C0 + C1, 3, 3).double(),
+                   bias.double(), padding=1) + res[:2].permute(0, 3, 1, 2).double()
+    assert common.rel_l2(o0[:2].permute(0, 3, 1, 2).float().cpu(), ref.float().cpu()) < 6e-3
 
 
 def test_conv2d_is_transpose_detecting_identity_weights():
