@@ -99,3 +99,42 @@ def test_spawn_helper_is_a_no_op_under_a_launcher_or_on_one_device():
             del os.environ["WORLD_SIZE"]
         else:
             os.environ["WORLD_SIZE"] = old
+
+
+def _bad_ckpt_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, C.ROOT)
+    from ivid_amd import parallel
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env("gloo")
+    schema = C.schema_for(C.MINI)
+    sd = None
+    if rank == 0:
+        sd = C.synth_weights(C.MINI, 0)
+        sd["out.2.bias"] = torch.zeros(7)              # wrong shape
+        sd["not.a.parameter"] = torch.zeros(1)         # unexpected key
+        del sd["time_embed.1.bias"]                    # missing key
+    try:
+        parallel.broadcast_state_dict(schema, sd, device=torch.device("cpu"))
+        q.put((rank, "no error"))
+    except KeyError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bad_checkpoint_raises_on_every_rank_instead_of_hanging():
+    """strict load semantics across ranks: missing / unexpected keys and wrong shapes are detected on the source
+    rank and the verdict is exchanged BEFORE the payload, so the other ranks raise too instead of waiting in the broadcast."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bad_ckpt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "missing ['time_embed.1.bias']" in res[0] and "not.a.parameter" in res[0] and "out.2.bias" in res[0]
+    assert "rejected the checkpoint" in res[1]
