@@ -91,7 +91,8 @@ int ivid_unet_forward(void* handle, const void* x, const void* times, const void
  *   out_mode  : 0 NHWC dtype [N,H,W,Cout]; 1 fp32 NCHW [N,Cout,H,W] (final conv, adm.py:566)
  *   tile_cfg  : 0 auto; 1 = 128x128 tile / 4 waves; 2 = 256x256 / 8 waves (wide layers); 3 = 128x32 (Cout <= 32: the
  *               4-channel output conv); 4 = 512x128 / 8 waves (Cout <= 128: the small / SR models' first levels at the
- *               256x256 tile's LDS-read : MFMA ratio); 5 = 64x128 / 2 waves (tiny problems that leave CUs idle with tile 1).  The fp32 summation
+ *               256x256 tile's LDS-read : MFMA ratio); 5 = 64x128 / 2 waves (tiny problems that leave CUs idle with tile 1); 6 = 128x384 / 8 waves (Cout % 384 == 0
+ *               when the 256x256 tile would leave a fractional last round of workgroups).  The fp32 summation
  *               order of `stats` is the same for every tile
  *   stats     : NULL, or fp32 [N*H*W/blk][Cout][2]: per block of blk consecutive pixels and output channel, sum and sum
  *               of squares of the stored output — the GroupNorm partial statistics of the NEXT layer, fused into this

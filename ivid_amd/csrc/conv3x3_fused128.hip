@@ -92,8 +92,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
   const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;
 
   // ---- halo staging: thread handles channel piece cpc = tid&3 (16 bytes of the 64-byte chunk) of halo pixels
-  //      hrow = 128 j + (tid>>2),
-  //      j = 0..5.  Per piece only the source pixel index is kept (6 VGPRs + one validity bit mask). ----
+  //      hrow = 128 j + (tid>>2), j = 0..4.  Per piece only the source pixel index is kept (5 VGPRs + one validity bit mask). ----
   const int cpc = tid & 3;
   const int hrow0 = tid >> 2;
   int pix[PIECES];       // source pixel index INSIDE the image (0 when padded / idle: valid memory, zeroed later)
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
     pix[j] = ok ? ys * Ws + xs : 0;
     okbits |= (ok ? 1u : 0u) << j;
   }
-  // LDS byte of this thread's piece inside a halo row (piece j adds 64 j rows)
+  // LDS byte of this thread's piece inside a halo row (piece j adds 128 j rows)
   const int st_lds = hrow0 * AROW + cpc * 16;
   const bool act5 = hrow0 < HROWS - 4 * 128;    // the last piece (j = 4) exists for the first 100 halo rows only
   // wave-uniform description of where channel chunk ch lives (src0 or the skip tensor src1): addresses are a
@@ -140,11 +139,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
   auto ab_store = [&](const f32x4& q, char* sAdst) {
     if (wave == 0 && lane < BKE / 2) *(f32x4*)(sAdst + lane * AROW + CHB) = f32x4{q[0], q[2], q[1], q[3]};
   };
-  // store of one transformed halo piece (fp32 lanes f[VE]) into the halo image, zero outside the image.
-  // bf16x3: the piece is 4 channels; its bf16 hi / lo halves go to 8-byte slots of the hi piece (2g) and the lo piece
-  // (2g+1) of the 8-channel group g = cpc>>1 the MFMA fragments are read from.
+  // store of one transformed halo piece (fp32 lanes f[VE]) into the halo image, zero outside the image
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   auto store_piece = [&](int j, const float* f, char* sAdst) {
     const unsigned keep = (okbits >> j) & 1 ? 0xffffffffu : 0u;
     {
@@ -217,7 +213,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
     ab_store(q0, sA0);
     wait_vmcnt0();
     __syncthreads();  // coefficients of chunk 0 visible
-    // all six pieces in lockstep: they share the channel piece, hence the coefficients (read once), and their 6 x VE/2
+    // all five pieces in lockstep: they share the channel piece, hence the coefficients (read once), and their 5 x VE/2
     // independent exp/rcp chains overlap instead of running one piece after the other (pipeline fill, no MFMA yet)
     {
       const char* cf = sA0 + CHB + cpc * (VE / 2) * AROW;

@@ -245,19 +245,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   // tree over the bits of (row mod VE), lowest bit first.  A 128-wide wave tile covers fewer rows per pass (RPP = VE/2):
   // it keeps NA = 2 accumulators per lane (row mod VE = lr and lr + RPP), runs the tree over the lane bits first and
   // adds the two accumulators last -- the same association.
-  constexpr int NA = WTN > 64 ? WTN / 64 : 1;
+  // (A 96-wide wave tile -- the 128 x 384 tile -- needs 12 lanes per slab row: it allocates 16, the last 4 idle, which
+  // gives it the 128-wide tile's row schedule and therefore the same two-accumulator order.)
+  constexpr int LPRN = WTN / VE;                                           // lanes a slab row needs
+  constexpr int LPR = LPRN <= 4 ? 4 : LPRN <= 8 ? 8 : LPRN <= 16 ? 16 : 32;   // lanes per slab row (power of two)
+  constexpr int RPP = 64 / LPR;   // rows per pass
+  constexpr int NPS = 32 / RPP;   // passes per fragment
+  constexpr int NA = RPP < VE ? VE / RPP : 1;
   float st_s[NA][VE], st_q[NA][VE];
+  const int nbase = n0 + wn * WTN;
+  const int lr = lane / LPR;
+  const bool lane_on = (lane - lr * LPR) < LPRN;                            // idle lanes of a padded row do nothing
+  const int lc = lane_on ? (lane - lr * LPR) * VE : (1 << 28);              // ... because their channel fails every n < Cout test
   float bv[VE];              // this lane's bias values (NHWC path): the same 16-byte channel piece in every pass
   {
-    const int nb = n0 + wn * WTN + (lane % (WTN / VE)) * VE;
+    const int nb = nbase + lc;
 #pragma unroll
     for (int e = 0; e < VE; ++e) bv[e] = (p.bias && nb < Cout) ? p.bias[nb + e] : 0.f;
   }
-  constexpr int LPR = WTN / VE;   // lanes per slab row
-  constexpr int RPP = 64 / LPR;   // rows per pass
-  constexpr int NPS = 32 / RPP;   // passes per fragment
-  const int nbase = n0 + wn * WTN;
-  const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
   // same-size residual: the loads of ALL fragments of the wave are issued up front, in one batch -- one memory latency
   // for the whole epilogue instead of one per fragment; their latency hides behind the first transpose
   // (fp32 storage: a fragment's residual is 8 pieces per lane -- batching all fragments would spill, so those modes keep
@@ -430,12 +435,20 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 //   1: 128 x 128, 4 waves 2x2, wave  64 x 64  (4 reads / 4 MFMA)   everything else; two workgroups per CU
 //   5:  64 x 128, 2 waves 1x2, wave  64 x 64  (4 reads / 4 MFMA)   tiny problems (8^2 levels at small batch): twice the
 //                                                                   workgroups of tile 1 when that one leaves CUs idle
+//   6: 128 x 384, 8 waves 2x4, wave  64 x 96  (5 reads / 6 MFMA)   Cout a multiple of 384 when tile 2 would leave a fractional
+//                                                                   last round (768 channels at 16^2, batch 128: 384 tiles of
+//                                                                   256 x 256 = 1.5 rounds of 256 CUs, 512 of these = 2 rounds)
 //   3: 128 x 32,  4 waves 4x1                                       Cout <= 32 (the 4-channel output conv)
 static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg) {
   int cfg = tile_cfg & 7;
   if (cfg != 0) return cfg;
   if (Cout <= 32) return 3;
   const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
+  if (Cout % 384 == 0 && big >= 256) {   // occupancy of the last round: tile 2 vs tile 6
+    const long long t6 = ((M + 127) / 128) * (Cout / 384);
+    const double e2 = (double)big / (double)(((big + 255) / 256) * 256), e6 = (double)t6 / (double)(((t6 + 255) / 256) * 256);
+    if (e2 < 0.8 && e6 > e2 + 0.1) return 6;
+  }
   if (Cout >= 256 && big >= 384) return 2;
   if (Cout <= 128 && Cout > 64 && (M + 511) / 512 >= 256) return 4;
   const long long mid = ((M + 127) / 128) * ((Cout + 127) / 128);
@@ -465,7 +478,7 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   a.stats = stats;
   hipStream_t s = (hipStream_t)stream;
   tile_cfg = ivid_conv_pick_tile(a.M, Cout, tile_cfg);
-  if (tile_cfg < 1 || tile_cfg > 5) return ivid_set_error("conv: tile_cfg must be 0 (auto) .. 5", hipSuccess);
+  if (tile_cfg < 1 || tile_cfg > 6) return ivid_set_error("conv: tile_cfg must be 0 (auto) .. 6", hipSuccess);
   if (stats) {  // a statistics block must not straddle two images
     const int gran = tile_cfg == 3 ? 32 : 64;
     if (out_mode != 0 || (H * W) % gran) return ivid_set_error("conv: stats need NHWC output and H*W % block == 0", hipSuccess);
@@ -476,6 +489,7 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
     if (tile_cfg == 3) return launch_conv<TT, 128, 32, 4, 1>(a, s);        \
     if (tile_cfg == 4) return launch_conv<TT, 512, 128, 8, 1>(a, s);       \
     if (tile_cfg == 5) return launch_conv<TT, 64, 128, 1, 2>(a, s);        \
+    if (tile_cfg == 6) return launch_conv<TT, 128, 384, 2, 4>(a, s);       \
     return launch_conv<TT, 128, 128, 2, 2>(a, s);                          \
   } while (0)
   if (dtype == IVID_BF16) IVID_CONV_DISPATCH(__bf16);

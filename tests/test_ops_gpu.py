@@ -82,6 +82,9 @@ CONV_CASES = [
     ("3x3_tile512x128_mtail_concat", 3, 24, 24, 64, 64, 96, 3, 0, 0, 4),
     ("1x1_tile512x128_auto_big_m", 8, 128, 128, 64, 0, 128, 1, 0, 0, 0),
     ("3x3_tile64x128_res_up", 2, 16, 16, 128, 0, 192, 3, 2, 0, 5),
+    ("3x3_tile128x384_res_c768", 2, 16, 16, 128, 0, 768, 3, 1, 0, 6),
+    ("1x1_tile128x384_concat_c384_mtail", 3, 8, 8, 64, 64, 384, 1, 0, 0, 6),
+    ("3x3_tile128x384_auto_c768_m32768", 128, 16, 16, 64, 0, 768, 3, 0, 0, 0),
     ("3x3_tile64x128_auto_tiny", 4, 8, 8, 128, 0, 256, 3, 1, 0, 0),
 ]
 
@@ -118,20 +121,20 @@ def test_conv2d_output_and_statistics_do_not_depend_on_the_tile(dtype):
     ragged batches, different ranks).  Outputs AND the fused GroupNorm partial sums must be bit-identical for every tile --
     including the fp32 summation order of the statistics (128-wide wave tiles emulate the 64-wide order)."""
     L = G.lib()
-    N, H, W, Cin, Cout = 4, 32, 32, 64, 128
+    N, H, W, Cin, Cout = 4, 32, 32, 64, 384
     x = G.to_nhwc(common.seeded_randn(1, N, Cin, H, W), dtype)
     w = G.pack_w((common.seeded_randn(2, Cout, Cin, 3, 3) / 24).permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
     b = (common.seeded_randn(3, Cout) * 0.1).cuda()
     res = G.to_nhwc(common.seeded_randn(4, N, Cout, H, W), dtype)
     outs = {}
-    for cfg in (1, 2, 4, 5):
+    for cfg in (1, 2, 4, 5, 6):
         out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
         st = torch.full((N * H * W // 64, Cout, 2), float("nan"), device="cuda")
         L.call("ivid_conv2d", dtype, L.ptr(x), Cin, None, 0, L.ptr(w), L.ptr(b), L.ptr(out), L.ptr(res), 1, 0, N, H, W, Cout, 9, cfg,
                L.ptr(st), G.stream())
         torch.cuda.synchronize()
         outs[cfg] = (out, st)
-    for cfg in (2, 4, 5):
+    for cfg in (2, 4, 5, 6):
         assert torch.equal(outs[cfg][0], outs[1][0]), f"outputs differ between tile 1 and tile {cfg}"
         assert torch.equal(outs[cfg][1], outs[1][1]), f"statistics differ between tile 1 and tile {cfg}"
 
