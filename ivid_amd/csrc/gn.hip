@@ -94,8 +94,9 @@ constexpr int FIN_NT = 256;
 
 // One block per (image, group).  The partial sums of a group are a [nchunks][cpg] matrix per source tensor (row = 8*cpg
 // contiguous bytes inside a [nchunks][C][2] array): thread t takes channel t % cpg of chunks t / cpg, t / cpg + 256/cpg, ...
-// so that a wave reads whole rows, and the 4..16 independent loads per thread overlap (the 64-thread version of round 1
-// walked up to 16 strided loads per thread back to back: 9 us per launch, 87 launches per forward).  fp64 accumulation;
+// so that a wave reads whole rows and a thread walks at most 4 loads back to back (the 64-thread version of round 1 walked up
+// to 16: 9.7 us per launch by rocprofv3, 87 launches per forward; this one 6.2 us; ONE 1024-thread block per image, 32 threads
+// per group, measured 7.7 us -- the time is the serial load -> fp64-add chain, not the dispatch of the 4096 small blocks).  fp64 accumulation;
 // the cross-thread reduction is a fixed tree (shuffles, then one LDS pass over the 4 waves): deterministic.
 __global__ __launch_bounds__(FIN_NT) void gn_finalize_kernel(const float* __restrict__ partial, int C0,
                                                              const float* __restrict__ partial1, int nchunks,
@@ -268,7 +269,7 @@ extern "C" int ivid_gn_finalize(const float* partial, int nchunks, int N, int C,
                                 int film_off, float* ab, void* stream) {
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize: C must be divisible by groups", hipSuccess);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(FIN_NT), 0, (hipStream_t)stream, partial, C, nullptr, nchunks,
-                     0, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
+                       0, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize");
 }
 
@@ -280,7 +281,7 @@ extern "C" int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, co
   if (groups <= 0 || C % groups) return ivid_set_error("gn_finalize2: C must be divisible by groups", hipSuccess);
   if (C1 > 0 && !partial1) return ivid_set_error("gn_finalize2: partial1 missing", hipSuccess);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(FIN_NT), 0, (hipStream_t)stream, partial0, C0, partial1, nchunks0,
-                     nchunks1, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
+                       nchunks1, C, HW, groups, eps, gamma, beta, film, film_stride, film_off, ab);
   return ivid_check_launch("gn_finalize2");
 }
 
