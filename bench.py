@@ -61,10 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default): BASELINE config 2, the headline metric.  c3: BASELINE config 3 end to end -- large uncond "
                          "(1000-step DDPM, CFG) + large cond (50-step DDIM, InpaintCFG) on the `random` viewset with the HIP "
-                         "depth-warp in the loop, bs 32: samples/s and the share of the time spent outside the UNet")
+                         "depth-warp in the loop, bs 32: samples/s and the share of the time spent outside the UNet.  c4: the same "
+                         "on the `3x9` viewset (27 views per sample, 26 warped / inpainted).  c5: c4 + the 128->256 super-resolution "
+                         "chain on every view (SR model, 50-step DDIM, CFG).  One batch of 32 samples per rank")
     ap.add_argument("--c3-steps-uncond", type=int, default=1000)
     ap.add_argument("--c3-steps-cond", type=int, default=50)
     ap.add_argument("--launcher-dry-run", action="store_true",
@@ -228,7 +230,7 @@ def main():
     from ivid_amd.diffusion import frameworks, samplers
     from ivid_amd.diffusion.backbones import AdmUnet2d
 
-    if a.config == "c3":
+    if a.config in ("c3", "c4", "c5"):
         return bench_c3(a, rank, world, dev, C, parallel, dist)
 
     margs = dict({"large": C.LARGE128, "small": C.SMALL128, "sr256": C.SR256}[a.model])
@@ -446,17 +448,35 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
     fc = frameworks.InpaintCFG(mc, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
     seeds = [rank * bs + i for i in range(bs)]
     classes = [s % 1000 for s in seeds]
-    views = camera.viewset("random", bs, np.random.default_rng(rank))
+    views = camera.viewset("random", bs, np.random.default_rng(rank)) if a.config == "c3" else camera.viewset("3x9")
+    nviews = 2 if a.config == "c3" else 27
+    fsr = None
+    if a.config == "c5":      # rgbd_imagenet_adm_256_128_small_sr.json: SuperResCFG on every generated view (BASELINE config 5)
+        from ivid_amd.inference.superres import super_resolve
+        msr = model(C.SR256, 6)
+        fsr = frameworks.SuperResCFG(msr, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
 
-    def run(n_u, n_c):
-        return list(sample_all(fu, fc, seeds, n_u, n_c, views, classes=classes, guidance=3.0, batchsize=bs))
+    sr_seconds = [0.0]
+
+    def run(n_u, n_c, sr_steps=50):
+        out = list(sample_all(fu, fc, seeds, n_u, n_c, views, classes=classes, guidance=3.0, batchsize=bs))
+        if fsr is not None:   # the chain uncond -> warp/inpaint views -> SR stays on the GPU (inference/sample.py of this package)
+            torch.cuda.synchronize(dev)
+            q0 = time.perf_counter()
+            hi = [super_resolve(fsr, smp, classes=classes[i], steps=sr_steps, strength=3.0, batchsize=16) for i, (smp, _) in enumerate(out)]
+            torch.cuda.synchronize(dev)
+            sr_seconds[0] = time.perf_counter() - q0
+            assert all(torch.isfinite(h).all() for h in hi)
+        return out
 
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
-    run_short(fu, fc, seeds, views, classes, bs, sample_all)   # warm-up: plans, hipGraphs, warp buffers (no 1000-step chain)
+    run_short(fu, fc, seeds, views if a.config == "c3" else views[:2], classes, bs, sample_all)   # warm-up: plans, hipGraphs (no 1000-step chain)
+    if fsr is not None:
+        super_resolve(fsr, torch.randn(nviews, 4, 128, 128, device=dev).clamp(-1, 1), classes=1, steps=2, strength=3.0, batchsize=16)
     fence()
     t0 = time.perf_counter()
     res = run(su, sc)
@@ -481,21 +501,29 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - q0) * 100.0
     mu_ms, mc_ms = fwd_ms(mu, 4), fwd_ms(mc, 10)
-    unet_s = (su * mu_ms + sc * mc_ms) / 1e3
+    unet_s = (su * mu_ms + (nviews - 1) * sc * mc_ms) / 1e3
+    label = {"c3": "config 3 (uncond + cond iterative `random` viewset)", "c4": "config 4 (`3x9` multiview, 27 views per sample)",
+             "c5": "config 5 (`3x9` multiview + 128->256 super-resolution of every view)"}[a.config]
     out = {
-        "metric": "samples/s end to end, BASELINE config 3 (uncond + cond iterative `random` viewset)",
-        "value": round(bs * world / dt, 4), "unit": "samples/s (2 views each: 1 unconditional + 1 warped/inpainted)",
+        "metric": "samples/s end to end, BASELINE " + label,
+        "value": round(bs * world / dt, 4), "unit": "samples/s (%d views each: 1 unconditional + %d warped/inpainted)" % (nviews, nviews - 1),
         "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded random-init weights)",
         "config": {"workload": "rgbd_imagenet_adm_128_large_cfg (DDPM %d steps, CFG 3.0) + rgbd_imagenet_adm_128_large_cond "
-                               "(DDIM %d steps, InpaintCFG 3.0), viewset random, bs=%d per GPU, HIP depth-warp in the loop" % (su, sc, bs),
+                               "(DDIM %d steps, InpaintCFG 3.0), viewset %s, bs=%d per GPU, HIP depth-warp in the loop%s"
+                               % (su, sc, "random" if a.config == "c3" else "3x9", bs,
+                                  ", + rgbd_imagenet_adm_256_128_small_sr (SuperResCFG 3.0, DDIM 50) on all %d views" % nviews if fsr is not None else ""),
                    "parallelism": "sample-parallel x%d" % world},
         "seconds_per_batch": round(dt, 3),
         "unet_forward_ms": {"uncond_stacked_bs%d" % (2 * bs): round(mu_ms, 3), "cond_stacked_bs%d" % (2 * bs): round(mc_ms, 3)},
         "unet_seconds_per_batch": round(unet_s, 3),
-        "share_outside_unet": round(max(0.0, 1.0 - unet_s / dt), 4),
-        "sample_fwd_per_s_end_to_end": round(2 * bs * (su + sc) * world / dt, 1),
+        "share_outside_unet": round(max(0.0, 1.0 - (unet_s + sr_seconds[0]) / dt), 4),
+        "sample_fwd_per_s_end_to_end": round(2 * bs * (su + (nviews - 1) * sc) * world / dt, 1),
     }
+    if fsr is not None:
+        out["sr_seconds_per_batch"] = round(sr_seconds[0], 3)
+        out["sr_views_per_s"] = round(bs * nviews / sr_seconds[0], 2)
+        out["config4_samples_per_s_same_run"] = round(bs * world / (dt - sr_seconds[0]), 4)     # the run minus its SR stage = config 4
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
