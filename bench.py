@@ -457,6 +457,25 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         fsr = frameworks.SuperResCFG(msr, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
 
     sr_seconds = [0.0]
+    # time spent in the depth-warp (meshing of a new view; z-buffer + aggregation + resolve of a target view): the two
+    # renderer entry points of sample_all, bracketed by device syncs (one pair per view: no measurable perturbation)
+    from ivid_amd import rgbd_3d
+    warp_s = {"conditions": 0.0, "add_view": 0.0, "calls": 0}
+
+    def timed_method(name):
+        inner = getattr(rgbd_3d.WarpRenderer, name)
+
+        def f(self, *aa, **kw):
+            torch.cuda.synchronize(dev)
+            q0 = time.perf_counter()
+            r = inner(self, *aa, **kw)
+            torch.cuda.synchronize(dev)
+            warp_s[name] += time.perf_counter() - q0
+            warp_s["calls"] += 1
+            return r
+        setattr(rgbd_3d.WarpRenderer, name, f)
+    timed_method("conditions")
+    timed_method("add_view")
 
     def run(n_u, n_c, sr_steps=50):
         out = list(sample_all(fu, fc, seeds, n_u, n_c, views, classes=classes, guidance=3.0, batchsize=bs))
@@ -478,6 +497,7 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
     if fsr is not None:
         super_resolve(fsr, torch.randn(nviews, 4, 128, 128, device=dev).clamp(-1, 1), classes=1, steps=2, strength=3.0, batchsize=16)
     fence()
+    warp_s.update(conditions=0.0, add_view=0.0, calls=0)
     t0 = time.perf_counter()
     res = run(su, sc)
     fence()
@@ -520,6 +540,10 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         "share_outside_unet": round(max(0.0, 1.0 - (unet_s + sr_seconds[0]) / dt), 4),
         "sample_fwd_per_s_end_to_end": round(2 * bs * (su + (nviews - 1) * sc) * world / dt, 1),
     }
+    out["warp_seconds_per_batch"] = {"conditions (z-buffer + aggregate + resolve)": round(warp_s["conditions"], 3),
+                                     "add_view (depth_to_mesh)": round(warp_s["add_view"], 3),
+                                     "note": "random-init weights generate NOISE depth maps: every quad of every mesh is a depth "
+                                             "discontinuity, the worst case for the rasteriser (smooth scenes: profiles/r01_pipeline_bench.json)"}
     if fsr is not None:
         out["sr_seconds_per_batch"] = round(sr_seconds[0], 3)
         out["sr_views_per_s"] = round(bs * nviews / sr_seconds[0], 2)

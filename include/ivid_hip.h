@@ -256,8 +256,10 @@ int ivid_mesh_build(const float* rgbd, int B, int S, const float* inv_modelview,
  *   outputs : color8 u8 [B][R][R][3] (to8b of the resolved colour), depth_lin fp32 [B][R][R] (metric depth),
  *             mask_color / mask_depth u8 [B][R][R]
  *   work / work_cap   : caller-owned queue of the LARGE triangles (skirt / discontinuity sheets seen from another
- *                       camera): int32 [2 + 2*work_cap]; they are rasterised by one workgroup each in a second pass
- *                       instead of by their own thread.  work_cap = 0 disables the second pass (slow, same result).
+ *                       camera; every triangle of a noisy depth map): int32 [2 + work_cap], one id per entry; they are
+ *                       rasterised by one wave each in a second pass (8x8-pixel tiles, one tile test per lane) instead
+ *                       of by their own thread.  NV*B*2*(S+1)^2 entries hold every triangle; a full queue or
+ *                       work_cap = 0 only costs speed (the triangle's own thread walks its box), the result is the same.
  *   color_f32         : NULL, or fp32 [B][R][R][3]: the colour BEFORE to8b, i.e. `color` of the edict that
  *                       AggregationRenderer.render returns (moderngl_renderer.py:317-319,333-338)
  * Pixel centres exactly on a triangle edge follow the top-left fill rule. */

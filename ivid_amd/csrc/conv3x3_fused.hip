@@ -54,7 +54,19 @@ struct FusedArgs {
   const char* sk1;
   const char* skw;     // [Cout][skC0+skC1]
   int skC0, skC1;
+#ifdef IVID_DEV_TIMELINE
+  unsigned long long* dbg;             // [blocks][8] phase time stamps (scripts/dev/fused_timeline.py)
+#endif
 };
+
+// Development build only (-DIVID_DEV_TIMELINE, never in the product library): thread 0 of every workgroup stamps the
+// 100 MHz real-time counter at its phase boundaries.
+#ifdef IVID_DEV_TIMELINE
+#define TL_STAMP(k) do { if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+unsigned long long* g_timeline = nullptr;
+#else
+#define TL_STAMP(k) do {} while (0)
+#endif
 
 constexpr int TH = 8, TW = 32;             // output tile (pixels)
 constexpr int HW_ = TW + 2, HH_ = TH + 2;  // halo
@@ -82,6 +94,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BYTES;
 
+  TL_STAMP(0);
+  TL_STAMP(1);
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   // tile id -> (image, tile row, tile col, cout tile); cout tiles of one pixel tile are neighbours (shared A in L2)
   const int tn = tile % p.ntiles_n;
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     ab_store(q0, sA0);
     wait_vmcnt0();
     __syncthreads();  // coefficients of chunk 0 visible
+    TL_STAMP(2);
     // all six pieces in lockstep: they share the channel piece, hence the coefficients (read once), and their 6 x VE/2
     // independent exp/rcp chains overlap instead of running one piece after the other (pipeline fill, no MFMA yet)
     {
@@ -464,10 +479,12 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // group 0 reads it.  Halo image c+1 is written in phase 1 of taps 3..8 of chunk c and first read after two more
   // barriers; its previous content was last read three steps before the first write.
   wait_vmcnt0();
+  TL_STAMP(3);
   if (wm == 1) __syncthreads();
   for (int ch = 0; ch + 1 < chunks; ++ch) chunk_body(ch, std::true_type{});
   chunk_body(chunks - 1, std::false_type{});
   if (wm == 0) __syncthreads();  // the two wave groups are aligned again
+  TL_STAMP(4);
 
   // ---------------- optional skip phase: acc += x[tile pixels] . Wskip  (the ResBlock's 1x1 skip_connection on its raw
   // input x = cat(sk0, sk1)); a plain 2-stage LDS-DMA pipeline like conv_igemm with taps = 1: A stage = the tile's 256
@@ -559,6 +576,7 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   }
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
+  TL_STAMP(5);
   constexpr int LDC = WTN + 4;
   constexpr int LPR = WTN / VE, RPP = 64 / LPR, NPS = 32 / RPP;   // lanes per slab row, rows per pass, passes per fragment
   const int Cout = p.Cout;
@@ -684,6 +702,13 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     }
     wave_lds_sync();  // the slab is private to this wave
   }
+#ifdef IVID_DEV_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of this wave retired
+  TL_STAMP(6);
+  if (p.dbg && threadIdx.x == 0)
+    p.dbg[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |       // HW_ID
+                                        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); // XCC_ID
+#endif
 }
 
 template <typename T> int launch_fused(const FusedArgs& a, hipStream_t stream) {
@@ -740,11 +765,18 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
+#ifdef IVID_DEV_TIMELINE
+  a.dbg = g_timeline;
+#endif
   if (dtype == IVID_BF16) return launch_fused<__bf16>(a, (hipStream_t)stream);
   if (dtype == IVID_F16) return launch_fused<_Float16>(a, (hipStream_t)stream);
   if (dtype == IVID_BF16X3) return launch_fused<bf16x3_t>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
 }
+
+#ifdef IVID_DEV_TIMELINE
+extern "C" void ivid_dev_timeline(void* buf) { g_timeline = (unsigned long long*)buf; }
+#endif
 
 extern "C" int ivid_conv3x3_gn(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                                const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,

@@ -286,7 +286,8 @@ constexpr int RASTER_SMALL = 256;  // bounding boxes up to this many pixels are 
 
 // Pass 1: one thread per triangle.  Small triangles (the height field proper: a few pixels each) are rasterised in
 // place; large ones -- skirt and discontinuity sheets seen from another camera, up to the whole target when a vertex is
-// behind the eye -- are queued for pass 2 so that no thread walks a big box alone.  work[0] = counter, entries (mb, t).
+// behind the eye; EVERY triangle of a noisy depth map -- are queued for pass 2 so that no thread walks a big box alone.
+// work[0] = counter, work[2 + i] = mesh * ntri + triangle.  The push is wave-aggregated (one atomic per wave).
 __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ verts, const unsigned char* __restrict__ diag,
                                                      int B, int P, const float* __restrict__ mvp, int R,
                                                      unsigned long long* __restrict__ zbuf, int* __restrict__ work,
@@ -301,11 +302,16 @@ __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ v
   if (!s.valid) return;
   int x0, x1, r0, r1;
   if (!tri_bbox(s, R, x0, x1, r0, r1)) return;
-  if ((x1 - x0 + 1) * (r1 - r0 + 1) > RASTER_SMALL && work_cap > 0) {
-    const int slot = atomicAdd(&work[0], 1);
+  const bool big = (x1 - x0 + 1) * (r1 - r0 + 1) > RASTER_SMALL && work_cap > 0;
+  const unsigned long long bigs = __ballot(big);
+  if (big) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)bigs) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&work[0], __popcll(bigs));
+    base = __shfl(base, leader);
+    const int slot = base + __popcll(bigs & ((1ull << lane) - 1ull));
     if (slot < work_cap) {
-      work[2 + 2 * slot] = (int)mb;
-      work[3 + 2 * slot] = t;
+      work[2 + slot] = (int)(mb * ntri + t);
       return;
     }  // queue full: fall through and walk it here (correct, only slower)
   }
@@ -318,21 +324,24 @@ __global__ __launch_bounds__(256) void raster_kernel(const float* __restrict__ v
     for (int x = x0; x <= x1; ++x) raster_pixel(s, pad, t, r, x, R, step, zb);
 }
 
-// Pass 2: one workgroup per queued triangle (grid-stride over the queue).  The box is cut into 16x16-pixel tiles; a wave
-// takes a tile, rejects it when one of the three (affine) edge functions is negative on all of it, else its 64 lanes
-// evaluate the 256 pixels.  Results are order-independent (atomicMin on (depth, id)).
+// Pass 2: one WAVE per queued triangle (grid-stride over the queue).  The box is cut into 8x8-pixel tiles; every lane
+// tests one tile (rejected when one of the three affine edge functions is negative on all of it), the survivors are
+// visited one after the other with one pixel per lane.  A sliver that crosses 100 pixels costs ~25 such visits instead
+// of a 10^4-pixel box walk.  Results are order-independent (atomicMin on (depth, id)).
 __global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict__ verts,
                                                          const unsigned char* __restrict__ diag, int B, int P,
                                                          const float* __restrict__ mvp, int R,
                                                          unsigned long long* __restrict__ zbuf,
                                                          const int* __restrict__ work, int work_cap, int nodiscard) {
-  const int Q = P - 1;
+  const int Q = P - 1, ntri = 2 * Q * Q;
   const int count = min(work[0], work_cap);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
+  const int wid = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   const double step = 2.0 / R;
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    const size_t mb = (size_t)work[2 + 2 * i];
-    const int t = work[3 + 2 * i];
+  for (int i = wid; i < count; i += nwaves) {
+    const unsigned entry = (unsigned)work[2 + i];
+    const size_t mb = entry / (unsigned)ntri;
+    const int t = (int)(entry - (unsigned)mb * (unsigned)ntri);
     const int b = (int)(mb % B);
     const float* V = verts + mb * P * P * 9;
     const TriSetup s = tri_setup(V, diag + mb * Q * Q, t, P, mvp + b * 16);
@@ -342,23 +351,31 @@ __global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 3; ++k) pad[k] = nodiscard ? 0.f : (float)((((int)V[(size_t)s.vi[k] * 9 + 8]) >> 1) & 1);
     unsigned long long* zb = zbuf + mb * R * R;
-    const int tx0 = x0 >> 4, ty0 = r0 >> 4;
-    const int ntx = (x1 >> 4) - tx0 + 1, nty = (r1 >> 4) - ty0 + 1;
-    for (int ti = wave; ti < ntx * nty; ti += 4) {
-      const int ty = ty0 + ti / ntx, tx = tx0 + ti % ntx;
-      const int px0 = max(x0, tx << 4), px1 = min(x1, (tx << 4) + 15), pr0 = max(r0, ty << 4), pr1 = min(r1, (ty << 4) + 15);
-      // pixel-centre extent of the tile in NDC
-      const double X0 = (px0 + 0.5) * step - 1.0, X1 = (px1 + 0.5) * step - 1.0;
-      const double Y0 = 1.0 - (pr1 + 0.5) * step, Y1 = 1.0 - (pr0 + 0.5) * step;
-      bool out = false;
+    const int tx0 = x0 >> 3, ty0 = r0 >> 3;
+    const int ntx = (x1 >> 3) - tx0 + 1, nty = (r1 >> 3) - ty0 + 1, nt = ntx * nty;
+    for (int base = 0; base < nt; base += 64) {
+      const int ti = base + lane;
+      bool keep = ti < nt;
+      if (keep) {
+        const int ty = ty0 + ti / ntx, tx = tx0 + ti % ntx;
+        const int px0 = max(x0, tx << 3), px1 = min(x1, (tx << 3) + 7), pr0 = max(r0, ty << 3), pr1 = min(r1, (ty << 3) + 7);
+        // pixel-centre extent of the tile in NDC
+        const double X0 = (px0 + 0.5) * step - 1.0, X1 = (px1 + 0.5) * step - 1.0;
+        const double Y0 = 1.0 - (pr1 + 0.5) * step, Y1 = 1.0 - (pr0 + 0.5) * step;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {  // max of the affine edge function over the tile
-        const double m = s.a[k] * (s.a[k] >= 0.0 ? X1 : X0) + s.b[k] * (s.b[k] >= 0.0 ? Y1 : Y0) + s.c[k];
-        out = out || m < 0.0;
+        for (int k = 0; k < 3; ++k) {  // max of the affine edge function over the tile
+          const double m = s.a[k] * (s.a[k] >= 0.0 ? X1 : X0) + s.b[k] * (s.b[k] >= 0.0 ? Y1 : Y0) + s.c[k];
+          keep = keep && !(m < 0.0);
+        }
       }
-      if (out) continue;
-      const int w = px1 - px0 + 1, n = w * (pr1 - pr0 + 1);
-      for (int p = lane; p < n; p += 64) raster_pixel(s, pad, t, pr0 + p / w, px0 + p % w, R, step, zb);
+      unsigned long long live = __ballot(keep);
+      while (live) {
+        const int j = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        const int tj = base + j;
+        const int pr = ((ty0 + tj / ntx) << 3) + (lane >> 3), px = ((tx0 + tj % ntx) << 3) + (lane & 7);
+        if (px >= x0 && px <= x1 && pr >= r0 && pr <= r1) raster_pixel(s, pad, t, pr, px, R, step, zb);
+      }
     }
   }
 }
@@ -653,6 +670,7 @@ extern "C" int ivid_warp_render(const float* verts, const unsigned char* diag, c
                                 float* color_f32, void* stream) {
   if (NV <= 0 || B <= 0 || R <= 0) return ivid_set_error("warp_render: bad size", hipSuccess);
   if (work_cap < 0 || (work_cap > 0 && !work)) return ivid_set_error("warp_render: bad work queue", hipSuccess);
+  if ((size_t)NV * B * 2 * (S + 1) * (S + 1) >= ((size_t)1 << 32)) return ivid_set_error("warp_render: too many triangles for the queue's 32-bit ids", hipSuccess);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)NV * B * R * R * sizeof(unsigned long long), s);
   if (e != hipSuccess) return ivid_set_error("warp_render: memset", e);

@@ -56,11 +56,12 @@ class WarpRenderer:
         self.scratch_depth = torch.empty(B, P * P, dtype=f32, device=dev)
         self.scratch_flags = torch.empty(B, P * P, dtype=torch.int32, device=dev)
         self.zbuf = torch.empty(NV, B, R * R, dtype=torch.int64, device=dev)
-        # queue of the large triangles (second rasterisation pass): counter + (mesh, triangle) pairs
-        # (skirt: 8 (S+1) triangles per mesh, + discontinuity sheets; 4096 per mesh leaves a 3x margin at S = 128 --
-        #  an overflowing queue only costs speed, the kernel then walks the triangle in its own thread)
-        self.work_cap = int(os.environ.get("IVID_WARP_QUEUE", str(NV * B * max(4096, 32 * (S + 1)))))
-        self.work = torch.zeros(2 + 2 * max(self.work_cap, 1), dtype=torch.int32, device=dev)
+        # queue of the large triangles (second rasterisation pass): counter + one id (mesh * ntri + triangle) per entry.
+        # Sized for EVERY triangle (4 B each: 115 MB at NV = 27, B = 32, S = 128): smooth scenes queue ~1150 per mesh (the
+        # skirt, 8 (S+1) triangles, + discontinuity sheets), but a noisy depth map makes every triangle a long sliver in
+        # the other views, and an overflowing queue falls back to one thread walking a box of up to R^2 pixels.
+        self.work_cap = int(os.environ.get("IVID_WARP_QUEUE", str(NV * B * 2 * (P - 1) * (P - 1))))
+        self.work = torch.zeros(2 + max(self.work_cap, 1), dtype=torch.int32, device=dev)
         self.color8 = torch.empty(B, R, R, 3, dtype=u8, device=dev)
         self.depth_lin = torch.empty(B, R, R, dtype=f32, device=dev)
         self.mask_c = torch.empty(B, R, R, dtype=u8, device=dev)

@@ -33,13 +33,14 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def warp_part():
+def warp_part(noise=False):
+    """noise=True: white-noise depth maps (what random-init weights generate): every triangle is a sliver in the other views."""
     from ivid_amd.rgbd_3d import WarpRenderer, camera
     B, S = 32, 128
     r = WarpRenderer(B, S, 3, 27)
     views = camera.viewset("3x9")
-    rgbd = torch.from_numpy(np.concatenate([WC.synthetic_rgbd(S, k) for k in range(B)])).cuda()
-    out = {"B": B, "S": S, "ssaa": 3}
+    rgbd = torch.from_numpy(np.concatenate([WC.synthetic_rgbd(S, k, layers="noise" if noise else False) for k in range(B)])).cuda()
+    out = {"B": B, "S": S, "ssaa": 3, "scene": "white-noise depth" if noise else "smooth surfaces + one step"}
     out["add_view_ms"] = round(timed(lambda: (r.reset(), r.add_view(rgbd, views[0])), 10), 3)
     r.reset()
     rows = []
@@ -89,7 +90,7 @@ def pipeline_part():
 
 
 if __name__ == "__main__":
-    out = {"warp": warp_part()}
+    out = {"warp": warp_part(), "warp_noise_depth": warp_part(noise=True)}
     if os.environ.get("SKIP_PIPELINE") != "1":
         out["pipeline"] = pipeline_part()
     print(json.dumps(out, indent=1))

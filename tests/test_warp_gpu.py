@@ -125,7 +125,7 @@ def test_mesh_build_full_size_batch_matches_oracle():
         assert d[:, :3].max() < 2e-6 and d.max() < 5e-5
 
 
-def _compare_render(S, ssaa, views, target, tag, B=2, layers=None, bars=(0.995, 0.99, 1e-2, 0.995)):
+def _compare_render(S, ssaa, views, target, tag, B=2, layers=None, bars=(0.995, 0.99, 1e-2, 0.995), min_hull=0.0):
     """views: list of source cameras (4x4, shared) or of [B,4,4] per-sample stacks; target likewise.  layers: per-view flags
     selecting the two-depth-layer scene family.  bars: (IoU depth mask, IoU colour mask, depth rel p99.9, colour-within-2 frac)."""
     R = S * ssaa
@@ -144,11 +144,11 @@ def _compare_render(S, ssaa, views, target, tag, B=2, layers=None, bars=(0.995, 
         ref = W.render(list(meshes), list(cols), per(target, b), 45, S, R)
         md, mc = hi.mask_depth[b].cpu().numpy().astype(bool), hi.mask_color[b].cpu().numpy().astype(bool)
         rd, rc = ref["mask_depth"][..., 0], ref["mask_color"][..., 0]
-        iou_d = (md & rd).sum() / max((md | rd).sum(), 1)
-        iou_c = (mc & rc).sum() / max((mc | rc).sum(), 1)
+        iou = lambda p, q: (p & q).sum() / (p | q).sum() if (p | q).any() else 1.0      # both empty: equal
+        iou_d, iou_c = iou(md, rd), iou(mc, rc)
         both = md & rd
         dg, dr_ = hi.depth[b].cpu().numpy(), ref["depth"][..., 0]
-        drel = np.abs(dg[both] - dr_[both]) / dr_[both]
+        drel = np.abs(dg[both] - dr_[both]) / dr_[both] if both.any() else np.zeros(1)
         # the visual hull (low-confidence pixels: skirts / discontinuity sheets, "farther z wins", aggregation.csh:27-34)
         hull_g, hull_r = (~md) & (dg > 0.0101), ref["lowconf"]
         iou_h = (hull_g & hull_r).sum() / max((hull_g | hull_r).sum(), 1)
@@ -157,7 +157,7 @@ def _compare_render(S, ssaa, views, target, tag, B=2, layers=None, bars=(0.995, 
         c8 = hi.color8[b].cpu().numpy().astype(int)
         r8 = (np.clip(ref["color"], 0, 1) * 255).astype(np.uint8).astype(int)
         cboth = mc & rc
-        cdiff = np.abs(c8[cboth] - r8[cboth]).max(axis=-1)
+        cdiff = np.abs(c8[cboth] - r8[cboth]).max(axis=-1) if cboth.any() else np.zeros(1)
         G.report(f"warp/render_{tag}_b{b}", iou_depth=iou_d, iou_color=iou_c, depth_rel_p999=float(np.quantile(drel, 0.999)),
                  depth_rel_median=float(np.median(drel)), color_exact_frac=float((cdiff == 0).mean()),
                  color_within2_frac=float((cdiff <= 2).mean()), coverage=float(md.mean()), clipped_triangles=float(ref["clipped"]),
@@ -165,6 +165,7 @@ def _compare_render(S, ssaa, views, target, tag, B=2, layers=None, bars=(0.995, 
         assert iou_d > bars[0] and iou_c > bars[1], (iou_d, iou_c)
         assert np.median(drel) < 1e-5 and np.quantile(drel, 0.999) < bars[2]
         assert (cdiff <= 2).mean() > bars[3]
+        assert hull_r.mean() >= min_hull
         if hull_r.mean() > 0.01:
             assert iou_h > 0.97 and np.quantile(hrel, 0.99) < 1e-2, (iou_h, float(np.quantile(hrel, 0.99)))
         # resolve: device kernels vs the numpy/Pillow restatement applied to the DEVICE's own hi-res buffers (pinned part)
@@ -202,6 +203,39 @@ def test_render_two_depth_layers_hull_rule():
     surfaces of the other (low-confidence 'farther z wins', aggregation.csh:27-34)."""
     _compare_render(64, 3, [WC.orbit(0.0, 0.0), WC.orbit(0.45, 0.0), WC.orbit(-0.3, 0.15)], WC.orbit(-0.6, -0.15), "layers_S64",
                     B=2, layers=[True, True, False], bars=(0.99, 0.98, 2e-2, 0.99))
+
+
+def test_render_white_noise_depth_all_triangles_are_slivers():
+    """Depth maps of a randomly initialised network (bench.py --config c4/c5): every triangle goes through the queued
+    second rasterisation pass.  Every vertex lies on a discontinuity, so no pixel is confident (both masks are empty on
+    both sides) and the whole picture is the low-confidence hull: its coverage and its "farther z wins" depth are compared."""
+    w = _compare_render(32, 3, [WC.orbit(0.0, 0.0), WC.orbit(0.45, 0.1)], WC.orbit(-0.5, -0.15), "noise_S32", B=2,
+                        layers=["noise", "noise"], bars=(0.97, 0.9, 5e-2, 0.9), min_hull=0.3)
+
+
+def test_raster_queue_paths_are_bit_identical():
+    """The z-buffer must not depend on WHO rasterises a triangle: its own thread (no queue), a wave of the second pass
+    (queue holds everything, the default), or a mix (a queue that overflows).  White-noise depth + a smooth scene."""
+    S, B = 32, 2
+    rgbds = [np.concatenate([WC.synthetic_rgbd(S, 10 * v + b, layers="noise" if v else False) for b in range(B)]) for v in range(3)]
+    views, target = [WC.orbit(0.0, 0.0), WC.orbit(0.45, 0.1), WC.orbit(-0.3, 0.0)], WC.orbit(-0.55, -0.15)
+    outs = []
+    for cap in (None, 0, 701):
+        r = renderer(B, S, 3, max_views=4)
+        ntri = 2 * (S + 1) * (S + 1)
+        assert r.work_cap == 4 * B * ntri                       # default: every triangle fits
+        if cap is not None:
+            r.work_cap = cap
+        for v, mv in enumerate(views):
+            r.add_view(torch.from_numpy(rgbds[v]).cuda(), mv, 45, 0.6, 5.0, 0.03, 0.03, 3)
+        hi = r.render(target, 45)
+        torch.cuda.synchronize()
+        queued = int(r.work[0].item())
+        outs.append((r.zbuf[:3].clone(), hi.color8.clone(), hi.depth.clone(), queued))
+    assert outs[0][3] > 0.3 * B * ntri and outs[1][3] == 0 and outs[2][3] > 701      # full / off / overflowing
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    G.report("warp/raster_queue_paths", queued_default=float(outs[0][3]), triangles=float(3 * B * ntri), identical=1.0)
 
 
 def test_render_per_sample_cameras_batch3():

@@ -7,12 +7,16 @@ from oracle import warp_oracle as W
 def synthetic_rgbd(S, seed, smooth_color=False, layers=False):
     """layers=True: a second scene family -- a near foreground slab (z ~ 0.75) floating in front of a far background
     (z ~ 1.9) with a hole in it: from another camera the discontinuity sheets and frustum skirts of one view cross the
-    surfaces of the others (the low-confidence "farther z wins" rule of aggregation.csh:27-34 decides those pixels)."""
+    surfaces of the others (the low-confidence "farther z wins" rule of aggregation.csh:27-34 decides those pixels).
+    layers="noise": white-noise depth in [0.7, 4] -- what a randomly initialised network generates: every quad is a
+    discontinuity and every triangle a long sliver in any other view (the rasteriser's worst case)."""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:S, 0:S] / (S - 1.0)
     z = 1.0 + 0.25 * np.exp(-((xx - 0.45) ** 2 + (yy - 0.55) ** 2) / 0.05) + 0.05 * np.sin(7 * xx) * np.cos(5 * yy)
     z[int(0.6 * S):, int(0.55 * S):] += 0.8
-    if layers:
+    if isinstance(layers, str) and layers == "noise":
+        z = rng.uniform(0.7, 4.0, (S, S))
+    elif layers:
         z = 1.9 + 0.1 * np.cos(4 * xx + seed) * np.sin(3 * yy)
         fg = (np.abs(xx - 0.5) < 0.28) & (np.abs(yy - 0.45) < 0.3) & ~((np.abs(xx - 0.55) < 0.07) & (np.abs(yy - 0.4) < 0.1))
         z[fg] = 0.75 + 0.05 * xx[fg]
