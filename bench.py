@@ -99,6 +99,19 @@ def conv_flops(args):
     return 2.0 * n * h * w * cout * taps * (c0 + c1), dtype
 
 
+def up_flops(args):
+    """Algorithmic FLOPs of one ivid_conv3x3_up launch: the reference's count for Upsample2d + Conv2d 3x3 (9 taps on the
+    2Hs x 2Ws output; the kernel executes 4/9 of these multiplications on phase-summed weights)."""
+    (_dtype, _s0, c0, _s1, c1, _w, _b, _o, n, hs, ws, cout, _tc, _st) = args
+    return 2.0 * n * (2 * hs) * (2 * ws) * cout * 9 * (c0 + c1)
+
+
+def up_bytes(args):
+    (dtype, _s0, c0, _s1, c1, _w, _b, _o, n, hs, ws, cout, _tc, _st) = args
+    esz = ESZ[dtype]
+    return float(n * hs * ws * (c0 + c1) * esz + n * 4 * hs * ws * cout * esz + 16 * cout * (c0 + c1) * esz)
+
+
 def fused_flops(args):
     """Algorithmic FLOPs of one ivid_conv3x3_gn[_skip] launch (2 x MACs; the GroupNorm/SiLU prologue counts 0)."""
     (_dtype, _s0, c0, _s1, c1, _ab, _up, _w, _b, _o, _r, _rm, n, h, w, cout, _st) = args[:17]
@@ -145,7 +158,7 @@ def cached_pmc_traffic():
 
 
 KERNEL_OF = {"ivid_conv3x3_gn": "conv3x3_fused_kernel", "ivid_conv3x3_gn_skip": "conv3x3_fused_kernel",
-             "ivid_conv2d": "conv_igemm_kernel", "ivid_attention": "attn_kernel", "ivid_conv3x3_gn_out": "conv3x3_out_kernel"}
+             "ivid_conv2d": "conv_igemm_kernel", "ivid_conv3x3_up": "conv_igemm_kernel", "ivid_attention": "attn_kernel", "ivid_conv3x3_gn_out": "conv3x3_out_kernel"}
 
 
 def kernel_table(prof, precision):
@@ -163,6 +176,9 @@ def kernel_table(prof, precision):
             fl, _ = conv_flops(args)
             f["flop"] += fl
             f["byt"] += conv_bytes(args, False)
+        elif name == "ivid_conv3x3_up":
+            f["flop"] += up_flops(args)
+            f["byt"] += up_bytes(args)
         elif name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip"):
             f["flop"] += fused_flops(args)
             f["byt"] += conv_bytes(args, True)
@@ -372,6 +388,10 @@ def main():
                     fl, _ = conv_flops(args)
                     rows.append(dict(n=args[11], h=args[12], cin=args[2] + args[4], cout=args[14], taps=args[15],
                                      res=args[9], ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+                elif name == "ivid_conv3x3_up":
+                    fl = up_flops(args)
+                    rows.append(dict(up4=1, n=args[8], h=2 * args[9], cin=args[2] + args[4], cout=args[11], taps=9, ms=round(ms, 4),
+                                     tflops=round(fl / ms / 1e9, 1)))
                 elif name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip"):
                     fl = fused_flops(args)
                     rows.append(dict(fused=1, n=args[12], h=args[13], cin=args[2] + args[4], cout=args[15], taps=9, up=args[6],

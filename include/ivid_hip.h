@@ -60,6 +60,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_EMBED_INPUTS 10   /* ivid_embed_inputs */
 #define IVID_OP_SILU_F32 11       /* ivid_silu_f32 */
 #define IVID_OP_STEM_IM2COL 12    /* ivid_stem_im2col */
+#define IVID_OP_CONV3X3_UP 13     /* ivid_conv3x3_up */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -104,6 +105,20 @@ int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, c
                 int tile_cfg, float* stats, void* stream);
 
 int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg);
+
+/* ---- Upsample2d (nearest x2) + Conv2d 3x3 of an `up` ResBlock's in_layers (adm.py:70-83 `F.interpolate(..., mode="nearest")`,
+ *      adm.py:203-206 `h = in_rest(x); h = self.h_upd(h); h = in_conv(h)`) without the upsampled tensor ----
+ * out[n, 2y+py, 2x+px, co] = bias[co] + sum_{a,b in {0,1}} sum_c cat(src0,src1)[n, y+py-1+a, x+px-1+b, c] * weight4[py*2+px][co][a*2+b][c]
+ * which equals conv3x3(pad0(nearest_x2(src))) when the host adds up the 3x3 taps that land on the same source pixel:
+ *   weight4[py*2+px][co][a*2+b][c] = sum_{ky in R(py,a)} sum_{kx in R(px,b)} w[co][c][ky][kx],
+ *   R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}
+ * (4/9 of the multiplications of the direct form; the sums are formed in fp32 before the conversion to `dtype`).
+ *   src0/src1 : the ACTIVATED source (ivid_gn_apply output), NHWC [N,Hs,Ws,C0/C1]; out NHWC [N,2Hs,2Ws,Cout]
+ *   weight4   : [4][Cout][4][C0+C1] in `dtype` (IVID_BF16X3: hi/lo split rows as for ivid_conv2d); Cout > 32
+ *   stats     : as ivid_conv2d, 64-pixel blocks of the OUTPUT image, 4*Hs*Ws/64 per image (Hs*Ws % 64 == 0);
+ *               block order inside an image: [phase][source block] */
+int ivid_conv3x3_up(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight4, const float* bias,
+                    void* out, int N, int Hs, int Ws, int Cout, int tile_cfg, float* stats, void* stream);
 
 /* ---- fused GroupNorm-apply (+FiLM) + SiLU [+ nearest x2 upsample] + Conv2d 3x3 (ResBlock2d in_layers / out_layers,
  *      adm.py:157-161,177-183,203-208,214-219) for W % 32 == 0, H % 8 == 0 ----

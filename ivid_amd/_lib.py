@@ -54,6 +54,7 @@ SIGNATURES = {
     "ivid_unet_forward": (i32, [vp, vp, vp, vp, vp, i32, vp]),
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
+    "ivid_conv3x3_up": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn_out": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ivid_conv3x3_gn_skip": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp,
@@ -85,7 +86,7 @@ SIGNATURES = {
 # op codes of the launch program (include/ivid_hip.h IVID_OP_*)
 OP_CODES = {"ivid_conv2d": 1, "ivid_conv3x3_gn": 2, "ivid_conv3x3_gn_skip": 3, "ivid_conv3x3_gn_out": 4, "ivid_gn_partial": 5,
             "ivid_gn_finalize": 6, "ivid_gn_finalize2": 7, "ivid_gn_apply": 8, "ivid_attention": 9, "ivid_embed_inputs": 10,
-            "ivid_silu_f32": 11, "ivid_stem_im2col": 12}
+            "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13}
 
 
 class Slot(C.Union):

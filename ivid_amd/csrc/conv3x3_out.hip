@@ -12,6 +12,10 @@
 //   schedule  : two barriers per CHUNK (not per tap): 36 MFMAs per wave between them; the 6 halo pieces of the next chunk
 //               are requested before the MFMAs and transformed in lockstep after them (16 accumulator VGPRs leave room
 //               to keep all six in flight)
+//   occupancy : ONE halo image (the transform of chunk c+1 overwrites it after the MFMAs of chunk c) + weight stages sized
+//               for the launch's Cout keep the workgroup at ~58 KB of LDS and <= 128 VGPRs, so TWO workgroups share a CU:
+//               one's transform (VALU / transcendental pipes) runs under the other's MFMAs and memory waits.  (The
+//               double-buffered single-workgroup form measured 1.7 TB/s: nothing overlapped its exp/rcp chains.)
 // The kernel is bound by the halo transform and the input stream, not by the matrix pipe.
 #include "common.h"
 #include "internal.h"
@@ -30,18 +34,24 @@ struct OutArgs {
 
 constexpr int TH = 8, TW = 32, HW_ = TW + 2, HH_ = TH + 2, HROWS = HH_ * HW_;
 constexpr int NT = 512, AROW = 144, A_BYTES = HROWS * AROW, PIECES = (HROWS + 63) / 64;
-constexpr int MAXCO = 16;                              // output channels the weight stages are sized for
-constexpr int B_BYTES = 9 * MAXCO * 128;               // one chunk, all taps
-constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;   // 134,784
+constexpr int MAXCO = 16;                              // most output channels a launch may have
+constexpr int COEF_BYTES = 32 * 16;                    // GroupNorm coefficients of one chunk: (a0,a1,b0,b1) per channel pair
+// One weight stage: 9 * Cout * 128 B, rounded up to whole waves of LDS-DMA (64 lanes x 16 B: the idle lanes of the last
+// wave write too)
+__host__ __device__ static inline int out_stage_bytes(int Cout) { return (9 * Cout * 8 + 63) / 64 * 1024; }
+// LDS of a launch: [halo image][2 coefficient sets][2 weight stages]
+static inline int out_lds_bytes(int Cout) { return A_BYTES + 2 * COEF_BYTES + 2 * out_stage_bytes(Cout); }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_out_kernel(const OutArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
   constexpr int BKE = 128 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA0 = smem;
-  char* const sB0 = smem + 2 * A_BYTES;
+  char* const sCf = smem + A_BYTES;
+  char* const sB0 = sCf + 2 * COEF_BYTES;
+  const int B_BYTES = out_stage_bytes(p.Cout);         // one chunk, all taps
 
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   const int tx = tile % p.tiles_x;
@@ -83,41 +93,46 @@ __global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
     if (wave == 0 && lane < BKE / 2) q = *(const f32x4*)(abn + (size_t)ch * BKE * 2 + lane * 4);
     return q;
   };
-  auto ab_store = [&](const f32x4& q, char* sAdst) {
-    if (wave == 0 && lane < BKE / 2) *(f32x4*)(sAdst + lane * AROW + 128) = f32x4{q[0], q[2], q[1], q[3]};
+  auto ab_store = [&](const f32x4& q, int set) {
+    if (wave == 0 && lane < BKE / 2) *(f32x4*)(sCf + set * COEF_BYTES + lane * 16) = f32x4{q[0], q[2], q[1], q[3]};
   };
-  // all six pieces in lockstep: shared coefficients (same channel piece), overlapping exp / rcp chains
-  auto xform_all = [&](const vec_t* raw, char* sAdst) {
-    const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
-    f32x4 q[VE / 2];
-#pragma unroll
-    for (int k = 0; k < VE / 2; ++k) q[k] = *(const f32x4*)(cf + k * AROW);
-    float f[PIECES][VE];
-#pragma unroll
-    for (int j = 0; j < PIECES; ++j) vec_to_f32<T>(raw[j], f[j]);
-#pragma unroll
-    for (int k = 0; k < VE / 2; ++k) {
-      f32x2 v[PIECES], d[PIECES];
-#pragma unroll
-      for (int j = 0; j < PIECES; ++j) {
-        v[j] = f32x2{f[j][2 * k], f[j][2 * k + 1]} * f32x2{q[k][0], q[k][1]} + f32x2{q[k][2], q[k][3]};
-        const f32x2 t = v[j] * -1.4426950408889634f;
-        d[j] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      }
-#pragma unroll
-      for (int j = 0; j < PIECES; ++j) {
-        d[j] = d[j] + 1.0f;
-        const f32x2 y = v[j] * f32x2{__builtin_amdgcn_rcpf(d[j][0]), __builtin_amdgcn_rcpf(d[j][1])};
-        f[j][2 * k] = y[0];
-        f[j][2 * k + 1] = y[1];
-      }
-    }
+  // three pieces at a time in lockstep: shared coefficients (same channel piece), 6 overlapping exp / rcp chains -- with
+  // four waves per SIMD resident that is enough to hide the transcendental latency, and it keeps the kernel at 128 VGPRs
+  auto xform_all = [&](const vec_t* raw, char* sAdst, int set) {
+    const char* cf = sCf + set * COEF_BYTES + cpc * (VE / 2) * 16;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int GP = VE == 8 ? 2 : 3;
 #pragma unroll
-    for (int j = 0; j < PIECES; ++j) {
-      u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f[j]));
-      ob &= (okbits >> j) & 1 ? 0xffffffffu : 0u;
-      if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * 64 * AROW) = ob;
+    for (int j0 = 0; j0 < PIECES; j0 += GP) {
+      float f[GP][VE];
+#pragma unroll
+      for (int j = 0; j < GP; ++j) vec_to_f32<T>(raw[j0 + j], f[j]);
+#pragma unroll
+      for (int k = 0; k < VE / 2; ++k) {
+        const f32x4 qk = *(const f32x4*)(cf + k * 16);   // re-read per group: 4 VGPRs live instead of 16
+        f32x2 v[GP], d[GP];
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          v[j] = f32x2{f[j][2 * k], f[j][2 * k + 1]} * f32x2{qk[0], qk[1]} + f32x2{qk[2], qk[3]};
+          const f32x2 t = v[j] * -1.4426950408889634f;
+          d[j] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        }
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          d[j] = d[j] + 1.0f;
+          const f32x2 y = v[j] * f32x2{__builtin_amdgcn_rcpf(d[j][0]), __builtin_amdgcn_rcpf(d[j][1])};
+          f[j][2 * k] = y[0];
+          f[j][2 * k + 1] = y[1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int jj = j0 + j;
+        u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f[j]));
+        ob &= (okbits >> jj) & 1 ? 0xffffffffu : 0u;
+        if (jj < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + jj * 64 * AROW) = ob;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // groups stay apart: the scheduler would otherwise unpack all six pieces first
     }
   };
   // weights of chunk ch, all taps: piece q = (tap * Cout + row) * 8 + pc  ->  LDS byte 16 q (lane-linear per wave)
@@ -145,10 +160,10 @@ __global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
     const f32x4 q0 = ab_load(0);
     issue_b(0, 0);
     load_pieces(0, raw);
-    ab_store(q0, sA0);
+    ab_store(q0, 0);
     wait_vmcnt0();
     __syncthreads();
-    xform_all(raw, sA0);
+    xform_all(raw, sA0, 0);
   }
   f32x16 acc;
 #pragma unroll
@@ -157,10 +172,9 @@ __global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
   for (int ch = 0; ch < chunks; ++ch) {
     const bool more = ch + 1 < chunks;
     wait_vmcnt0();
-    __syncthreads();  // halo(ch) complete, weights(ch) landed, everyone done with the other buffers
-    const char* aptr = sA0 + (ch & 1) * A_BYTES + a_base;
+    __syncthreads();  // halo(ch) complete, weights(ch) landed, everyone done with the other weight stage
+    const char* aptr = sA0 + a_base;
     const char* bptr = sB0 + (ch & 1) * B_BYTES + b_base;
-    char* sAn = sA0 + ((ch + 1) & 1) * A_BYTES;
     f32x4 abq = {0.f, 0.f, 0.f, 0.f};
     if (more) {
       issue_b((ch + 1) & 1, ch + 1);
@@ -177,10 +191,10 @@ __global__ __launch_bounds__(NT) void conv3x3_out_kernel(const OutArgs p) {
       }
     }
     if (more) {
-      ab_store(abq, sAn);
+      ab_store(abq, (ch + 1) & 1);
       wait_vmcnt0();
-      __syncthreads();  // coefficients of chunk ch+1 visible (its halo image is not read by anyone yet)
-      xform_all(raw, sAn);
+      __syncthreads();  // every wave is done reading the image of chunk ch; coefficients of chunk ch+1 visible
+      xform_all(raw, sA0, (ch + 1) & 1);
     }
   }
 
@@ -201,11 +215,11 @@ template <typename T> int launch_out(const OutArgs& a, hipStream_t stream) {
   auto kern = conv3x3_out_kernel<T>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, out_lds_bytes(MAXCO));
     if (e != hipSuccess) return ivid_set_error("conv3x3_gn_out: hipFuncSetAttribute", e);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles_total), dim3(NT), LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles_total), dim3(NT), out_lds_bytes(a.Cout), stream, a);
   return ivid_check_launch("conv3x3_gn_out");
 }
 

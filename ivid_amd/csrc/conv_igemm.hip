@@ -39,7 +39,8 @@ struct ConvArgs {
   int C0, C1;
   int N, H, W;
   int Cout;
-  int taps;      // 1 or 9
+  int taps;      // 1 or 9; 4 = phase-decomposed "nearest x2 upsample + conv 3x3" (ivid_conv3x3_up, see there)
+  int nt_phase;  // taps == 4: cout tiles per output phase (ntiles_n = 4 * nt_phase), else 0
   int res_mode;  // 0 none, 1 same size, 2 residual is (H/2,W/2) nearest-up, 3 residual is (2H,2W) avg-pool
   int out_mode;  // 0 NHWC T, 1 NCHW fp32
   int M;
@@ -63,7 +64,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
-  const int tm = tile / p.ntiles_n, tn = tile - tm * p.ntiles_n;
+  const int tm = tile / p.ntiles_n;
+  int tn = tile - tm * p.ntiles_n;
+  // taps == 4: the cout tiles of the four output phases (py, px) of one pixel tile are neighbours (shared A in L2)
+  int phase = 0;
+  if (p.nt_phase) {
+    phase = tn / p.nt_phase;
+    tn -= phase * p.nt_phase;
+  }
+  const int py = phase >> 1, px = phase & 1;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay in SGPRs
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     const int row = q >> 3, pos = q & 7;
     const int c = (pos ^ ((row >> 1) & 7)) * VE;
     const int co = n0 + row;
-    b_ptr[i] = (co < p.Cout) ? p.w + ((size_t)co * Ktot + c) * sizeof(T) : nullptr;
+    b_ptr[i] = (co < p.Cout) ? p.w + (((size_t)phase * p.Cout + co) * Ktot + c) * sizeof(T) : nullptr;
   }
 
   // K-loop order: channel-chunk-major, taps inner — the 9 shifted re-reads of one 128-byte channel slab are back to
@@ -123,6 +132,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     if (p.taps == 9) {
       dy = ld_tap / 3 - 1;
       dx = ld_tap - (dy + 1) * 3 - 1;
+    } else if (p.taps == 4) {  // tap (a, b) of output phase (py, px) reads the source pixel at (py - 1 + a, px - 1 + b)
+      dy = py - 1 + (ld_tap >> 1);
+      dx = px - 1 + (ld_tap & 1);
     }
     const int delta = ((dy * p.W + dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
 #pragma unroll
@@ -350,7 +362,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
             }
           }
           const vec_t ov = f32_to_vec<T>(v);
-          *(vec_t*)(p.out + ((size_t)m * Cout + n) * sizeof(T)) = ov;
+          size_t mo = (size_t)m;
+          if (p.taps == 4) {  // source pixel (img, y, x) of phase (py, px) -> output pixel (2y + py, 2x + px) of the 2H x 2W image
+            const int img = m / HW, rem = m - img * HW;
+            const int y = rem / p.W, x = rem - y * p.W;
+            mo = ((size_t)img * (2 * p.H) + 2 * y + py) * (2 * p.W) + 2 * x + px;
+          }
+          *(vec_t*)(p.out + (mo * Cout + n) * sizeof(T)) = ov;
           if (p.stats) {
             float sv[VE];
             vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
@@ -377,7 +395,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         const int n = nbase + lc;
         const int wbase = m0 + wm * WTM + (mi / FL) * (FL * 32);  // first pixel of this block
         if (lr == 0 && wbase < p.M && n < Cout) {
-          float* sp = p.stats + ((size_t)(wbase / (FL * 32)) * Cout + n) * 2;
+          size_t slot = (size_t)(wbase / (FL * 32));
+          if (p.taps == 4) {  // blocks of the 2H x 2W output image: [image][phase][source block] (any partition of an image works)
+            const int bpi = HW / (FL * 32), img = (int)slot / bpi;
+            slot = (size_t)img * (4 * bpi) + (size_t)phase * bpi + (slot - (size_t)img * bpi);
+          }
+          float* sp = p.stats + (slot * Cout + n) * 2;
 #pragma unroll
           for (int e = 0; e < VE; ++e)
 #pragma unroll
@@ -412,8 +435,9 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-  a.ntiles_n = nt;
-  a.ntiles_total = mt * nt;
+  a.nt_phase = a.taps == 4 ? nt : 0;
+  a.ntiles_n = a.taps == 4 ? 4 * nt : nt;
+  a.ntiles_total = mt * a.ntiles_n;
   auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -439,30 +463,32 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
 //                                                                   last round (768 channels at 16^2, batch 128: 384 tiles of
 //                                                                   256 x 256 = 1.5 rounds of 256 CUs, 512 of these = 2 rounds)
 //   3: 128 x 32,  4 waves 4x1                                       Cout <= 32 (the 4-channel output conv)
-static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg) {
+static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg, int nmult = 1) {   // nmult: cout-tile sets per pixel tile (4 in phase mode)
   int cfg = tile_cfg & 7;
   if (cfg != 0) return cfg;
   if (Cout <= 32) return 3;
-  const long long big = ((M + 255) / 256) * ((Cout + 255) / 256);
+  const long long big = ((M + 255) / 256) * ((Cout + 255) / 256) * nmult;
   if (Cout % 384 == 0 && big >= 256) {   // occupancy of the last round: tile 2 vs tile 6
-    const long long t6 = ((M + 127) / 128) * (Cout / 384);
+    const long long t6 = ((M + 127) / 128) * (Cout / 384) * nmult;
     const double e2 = (double)big / (double)(((big + 255) / 256) * 256), e6 = (double)t6 / (double)(((t6 + 255) / 256) * 256);
     if (e2 < 0.8 && e6 > e2 + 0.1) return 6;
   }
   if (Cout >= 256 && big >= 384) return 2;
-  if (Cout <= 128 && Cout > 64 && (M + 511) / 512 >= 256) return 4;
-  const long long mid = ((M + 127) / 128) * ((Cout + 127) / 128);
+  if (Cout <= 128 && Cout > 64 && (M + 511) / 512 * nmult >= 256) return 4;
+  const long long mid = ((M + 127) / 128) * ((Cout + 127) / 128) * nmult;
   if (mid < 256 && Cout >= 64) return 5;
   return 1;
 }
 
-extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
-                           const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
-                           int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
+static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
+                      const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
+                      int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
-  if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  if (taps != 1 && taps != 9 && taps != 4) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  if (taps == 4 && (res_mode != 0 || out_mode != 0 || Cout <= 32 || (H * W) % 64 || (long long)N * H * W * 4 >= (1ll << 31)))
+    return ivid_set_error("conv3x3_up: needs NHWC output without residual, Cout > 32, H*W % 64 == 0", hipSuccess);
   if (C0 <= 0 || C0 % bke || C1 < 0 || C1 % bke) return ivid_set_error("conv: channels must be multiples of the K-step", hipSuccess);
   if (C1 > 0 && !src1) return ivid_set_error("conv: src1 missing", hipSuccess);
   if (out_mode == 0 && Cout % ve) return ivid_set_error("conv: Cout must be a multiple of 16 bytes for NHWC output", hipSuccess);
@@ -474,10 +500,11 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page();
   if (!a.zero) return -1;
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
-  a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0;
+  a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0; a.nt_phase = 0;
   a.stats = stats;
   hipStream_t s = (hipStream_t)stream;
-  tile_cfg = ivid_conv_pick_tile(a.M, Cout, tile_cfg);
+  tile_cfg = ivid_conv_pick_tile(a.M, Cout, tile_cfg, taps == 4 ? 4 : 1);
+  if (taps == 4 && tile_cfg == 3) return ivid_set_error("conv3x3_up: the 128x32 tile is not available here", hipSuccess);
   if (tile_cfg < 1 || tile_cfg > 6) return ivid_set_error("conv: tile_cfg must be 0 (auto) .. 6", hipSuccess);
   if (stats) {  // a statistics block must not straddle two images
     const int gran = tile_cfg == 3 ? 32 : 64;
@@ -497,6 +524,26 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (dtype == IVID_BF16X3) IVID_CONV_DISPATCH(bf16x3_t);
   IVID_CONV_DISPATCH(float);
 #undef IVID_CONV_DISPATCH
+}
+
+extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
+                           const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
+                           int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
+  if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  return conv2d_any(dtype, src0, C0, src1, C1, weight, bias, out, res, res_mode, out_mode, N, H, W, Cout, taps, tile_cfg, stats,
+                    stream);
+}
+
+// Upsample2d (nearest x2, adm.py:70-83 inside an `up` ResBlock's h_upd, adm.py:203-206) followed by the block's Conv2d 3x3,
+// WITHOUT the upsampled tensor and with 4/9 of the multiplications: of the 3 x 3 taps an output pixel (2y + py, 2x + px)
+// sees, those that land on the same source pixel are added up on the host, which leaves a 2 x 2 convolution of the SOURCE
+// image per output phase (py, px):  rows {y-1 | y, y} for py = 0 and {y, y | y+1} for py = 1, columns likewise.  The zero
+// padding of the upsampled image coincides with zero padding of the source.  Implicit GEMM with M = N*Hs*Ws source pixels,
+// four cout-tile sets (one per phase) and K = 4 * C; the epilogue scatters every phase to its output pixels.
+extern "C" int ivid_conv3x3_up(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight4,
+                               const float* bias, void* out, int N, int Hs, int Ws, int Cout, int tile_cfg, float* stats,
+                               void* stream) {
+  return conv2d_any(dtype, src0, C0, src1, C1, weight4, bias, out, nullptr, 0, 0, N, Hs, Ws, Cout, 4, tile_cfg, stats, stream);
 }
 
 // Pixels per GroupNorm-statistics block that ivid_conv2d will write for this problem (depends on the tile it picks).

@@ -37,6 +37,8 @@ int run_op(const Op& o, void* s) {
     case IVID_OP_CONV2D:
       return ivid_conv2d(I(0), CP(1), I(2), CP(3), I(4), CP(5), CFP(6), P(7), CP(8), I(9), I(10), I(11), I(12), I(13), I(14), I(15),
                          I(16), FP(17), s);
+    case IVID_OP_CONV3X3_UP:
+      return ivid_conv3x3_up(I(0), CP(1), I(2), CP(3), I(4), CP(5), CFP(6), P(7), I(8), I(9), I(10), I(11), I(12), FP(13), s);
     case IVID_OP_CONV3X3_GN:
       return ivid_conv3x3_gn(I(0), CP(1), I(2), CP(3), I(4), CFP(5), I(6), CP(7), CFP(8), P(9), CP(10), I(11), I(12), I(13), I(14),
                              I(15), FP(16), s);

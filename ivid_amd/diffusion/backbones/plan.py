@@ -32,6 +32,22 @@ def split_pack(w2d):
     return torch.stack([hi.view(cout, k // 8, 8), lo.view(cout, k // 8, 8)], dim=2).reshape(cout, 2 * k).contiguous()
 
 
+def up4_weights(w):
+    """Conv2d 3x3 weights [Cout,Cin,3,3] -> the phase-summed form [4*Cout, 4*Cin] ivid_conv3x3_up takes
+    (rows [phase = py*2+px][cout], columns [tap = a*2+b][cin]): behind a nearest x2 upsample (adm.py:70-83, 203-206)
+    the 3x3 taps of output pixel (2y+py, 2x+px) that land on the same source pixel are added up, which leaves a 2x2
+    convolution of the source per phase -- rows {ky=0 | ky=1,2} for py = 0 and {ky=0,1 | ky=2} for py = 1, columns alike."""
+    cout, cin = w.shape[:2]
+    sets = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}    # (phase bit, tap bit) -> kernel rows / columns
+    out = w.new_empty(2, 2, cout, 2, 2, cin)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    out[py, px, :, a, b, :] = w[:, :, sets[(py, a)]][:, :, :, sets[(px, b)]].sum(dim=(2, 3))
+    return out.reshape(4 * cout, 4 * cin)
+
+
 def _pad_to(c, m):
     return (c + m - 1) // m * m
 
@@ -75,6 +91,8 @@ class PackedWeights:
             p = op.prefix
             if isinstance(op, Res):
                 vec(p + ".in_layers.0"); conv3(p + ".in_layers.2")
+                if op.mode == "up":   # phase-summed weights of upsample + conv (ivid_conv3x3_up), summed in fp32
+                    t[p + ".in_layers.2.weight_up4"] = mat(up4_weights(g(p + ".in_layers.2.weight")).contiguous())
                 vec(p + ".out_layers.0"); conv3(p + ".out_layers.3")
                 if op.has_skip_conv:
                     conv1(p + ".skip_connection")
@@ -148,6 +166,9 @@ class UNetPlan:
         self.fuse_conv = os.environ.get("IVID_NO_FUSED_CONV", "0") != "1"     # GN-apply+SiLU inside the 3x3 conv (W >= 32)
         self.fuse_skip = os.environ.get("IVID_NO_FUSED_SKIP", "0") != "1"     # 1x1 skip_connection inside that kernel too
         self.fuse_narrow = os.environ.get("IVID_NO_FUSED128", "0") != "1"     # Cout <= 128 through the 16x32x128 variant
+        # in_layers conv of an `up` ResBlock as four 2x2 phase convolutions of the low-resolution tensor (4/9 of the
+        # multiplications, csrc/conv_igemm.hip ivid_conv3x3_up) for sources up to this side; 0 disables it
+        self.up4_max_side = int(os.environ.get("IVID_UP4_MAX_SIDE", "1024"))
         self._sum_bias = {}
         self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
         self.taps = {}
@@ -303,7 +324,16 @@ class UNetPlan:
         fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         h1 = self._new(n, so, op.cout, stats=True)
-        if fused:
+        if (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0
+                and op.cout > 32):
+            # activated tensor at the SOURCE size (a quarter of the bytes of the upsampled one), then the phase convolution
+            act1 = self._gn(x, None, op.prefix + ".in_layers.0", None, 0, 1)
+            h1.stats_blk = 64
+            self._rec("ivid_conv3x3_up", self.dtype, act1.ptr, op.cin, None, 0,
+                      self.w[op.prefix + ".in_layers.2.weight_up4"].data_ptr(), self.w[op.prefix + ".in_layers.2.bias"].data_ptr(),
+                      h1.ptr, n, x.side, x.side, op.cout, self.tile_cfg, h1.stats.data_ptr() if h1.stats is not None else None)
+            self._free(act1)
+        elif fused:
             ab1 = self._gn_coeffs(x, skip, op.prefix + ".in_layers.0", None)
             self._conv3_gn(x, skip, ab1, op.mode == "up", op.prefix + ".in_layers.2", h1, None, 0)
             self.arena.put(ab1)

@@ -207,6 +207,28 @@ def test_cfg_branches_follow_the_reference_for_every_sign_of_strength():
     assert torch.allclose(cfg_combine(*cfg_branches(backbone, x, t, None, 3.0)), torch.full((2, 1), 3.0)) and calls == [False]
 
 
+def test_up4_weights_turn_upsample_plus_conv3x3_into_four_2x2_phase_convolutions():
+    """include/ivid_hip.h ivid_conv3x3_up: Upsample2d (nearest x2) -> Conv2d 3x3 pad 1 (adm.py:70-83, 203-206) equals, per
+    output phase (py, px), a 2x2 convolution of the zero-padded SOURCE with the phase-summed weights (exact in fp64)."""
+    import torch.nn.functional as F
+    from ivid_amd.diffusion.backbones.plan import up4_weights
+    w = C.seeded_randn(5, 6, 4, 3, 3).double()
+    x = C.seeded_randn(6, 2, 4, 5, 7).double()
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    w4 = up4_weights(w)
+    assert w4.shape == (4 * 6, 4 * 4)
+    w4 = w4.reshape(2, 2, 6, 2, 2, 4)                       # [py][px][cout][a][b][cin]
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):                           # source pixel (y + py - 1 + a, x + px - 1 + b)
+                    out[:, :, py::2, px::2] += torch.einsum("nchw,oc->nohw", xp[:, :, py + a:py + a + 5, px + b:px + b + 7],
+                                                            w4[py, px, :, a, b, :])
+    assert float((out - ref).abs().max()) < 1e-12
+
+
 def test_launch_program_object_records_ops_without_a_gpu():
     """csrc/program.hip: the C-side owner of a planned forward.  Creating, filling and destroying it needs no device; the
     slot packing follows each entry point's signature (floats as double, everything else as int64)."""
@@ -226,3 +248,37 @@ def test_launch_program_object_records_ops_without_a_gpu():
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in _lib.OP_CODES.items():
         assert re.search(rf"#define IVID_OP_{name[5:].upper()} {code}\b", hdr), name
+
+
+@pytest.mark.parametrize("cfg", ["MINI", "LARGE128", "SMALL128", "SR256"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_launch_plan_builds_without_a_gpu_and_every_launch_matches_its_c_signature(cfg, precision, monkeypatch):
+    """The launch plan is host logic: on torch's `meta` device it can be built without a GPU.  Every recorded launch must
+    pack against the ctypes signature of its entry point (argument count and kinds), the four `up` ResBlocks of the
+    five-level models go through ivid_conv3x3_up (two in the three-level mini model), and statistics come fused
+    (no ivid_gn_partial pass)."""
+    import collections
+    from ivid_amd import _lib
+    from ivid_amd.diffusion.backbones import plan as P
+    from ivid_amd.diffusion.backbones.spec import build_spec
+
+    class FakeStream:
+        def __init__(self, device=None):
+            self.cuda_stream = 0
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setenv("IVID_PY_LAUNCH", "1")           # no C-side program: binding it needs real device pointers
+    args = getattr(C, cfg)
+    spec = build_spec(**args)
+    sd = {k: torch.zeros(s) for k, s in C.schema_for(args)}
+    dt = _lib.PRECISIONS[precision]
+    pl = P.UNetPlan(spec, P.PackedWeights(spec, sd, "meta", dt), "meta", 2, True)
+    cnt = collections.Counter(name for _, name, _ in pl.launches)
+    for _fn, name, a in pl.launches:
+        _lib.pack_args(name, a)                          # asserts the argument count
+        assert name in _lib.OP_CODES, name
+    n_up = sum(1 for op in spec.res_ops() if op.mode == "up")
+    assert cnt["ivid_conv3x3_up"] == n_up == len(args["channel_mult"]) - 1
+    assert cnt["ivid_gn_partial"] == 0 and cnt["ivid_attention"] == sum(1 for st in spec.stages for op in st.ops if hasattr(op, "heads"))
+    for _fn, name, a in pl.launches:
+        if name == "ivid_conv3x3_up":                    # source side, channels: the activated low-resolution tensor
+            assert a[9] == a[10] and (a[9] * a[10]) % 64 == 0 and a[11] > 32

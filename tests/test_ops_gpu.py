@@ -115,6 +115,93 @@ def test_conv2d(case, dtype):
     assert e < G.tol(dtype), f"{name}: rel_l2 {e}"
 
 
+def phase_weights(w):
+    """include/ivid_hip.h ivid_conv3x3_up, written independently of the product's packer: [Cout,Cin,3,3] ->
+    [4 phases][Cout][4 taps][Cin]; kernel row ky contributes to tap a of phase py when the upsampled row 2y+py+ky-1
+    is a copy of source row y+py-1+a."""
+    cout, cin = w.shape[:2]
+    w4 = torch.zeros(4, cout, 4, cin, dtype=w.dtype)
+    for py in range(2):
+        for px in range(2):
+            for ky in range(3):
+                for kx in range(3):
+                    a = (py + ky - 1) // 2 - (py - 1)     # floor((2y+py+ky-1)/2) - (y+py-1) with y = 0
+                    b = (px + kx - 1) // 2 - (px - 1)
+                    w4[py * 2 + px, :, a * 2 + b, :] += w[:, :, ky, kx]
+    return w4
+
+
+UP_CASES = [
+    # name, N, Hs, Ws, C0, C1, Cout, tile_cfg
+    ("up_8to16_tile128", 2, 8, 8, 128, 0, 128, 1),
+    ("up_16to32_auto_c384", 2, 16, 16, 64, 0, 384, 0),
+    ("up_16to32_bigtile_mtail", 3, 16, 16, 128, 0, 320, 2),
+    ("up_nonsquare_concat", 1, 8, 16, 64, 64, 192, 5),
+    ("up_32to64_tile512x128", 2, 32, 32, 128, 0, 128, 4),
+    ("up_16to32_tile128x384", 2, 16, 16, 128, 0, 768, 6),
+    ("up_64to128_auto_c256", 2, 64, 64, 64, 0, 256, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", UP_CASES, ids=[c[0] for c in UP_CASES])
+def test_conv3x3_up_equals_upsample_then_conv(case, dtype):
+    """ivid_conv3x3_up (four 2x2 phase convolutions of the source, phase-summed weights) against the reference's own op
+    sequence Upsample2d -> Conv2d 3x3 (adm.py:70-83, 203-206: F.interpolate(nearest, x2) then conv, padding 1)."""
+    name, N, Hs, Ws, C0, C1, Cout, tile_cfg = case
+    if dtype in (0, 3) and (C0 % 32 or C1 % 32):
+        pytest.skip("K-step")
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    x0 = common.seeded_randn(s, N, C0, Hs, Ws)
+    x1 = common.seeded_randn(s + 1, N, C1, Hs, Ws) if C1 else None
+    w = common.seeded_randn(s + 2, Cout, C0 + C1, 3, 3) / np.sqrt((C0 + C1) * 9)
+    b = common.seeded_randn(s + 3, Cout) * 0.1
+    w4 = phase_weights(w)
+    d0 = G.to_nhwc(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
+    wp = G.pack_w(w4.reshape(4 * Cout, -1), dtype)
+    bd = b.cuda()
+    out = torch.full((N, 2 * Hs, 2 * Ws, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    nblk = N * 4 * Hs * Ws // 64
+    stats = torch.full((nblk, Cout, 2), float("nan"), device="cuda")
+    L.call("ivid_conv3x3_up", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(bd), L.ptr(out), N, Hs, Ws, Cout, tile_cfg,
+           L.ptr(stats), G.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    # fused GroupNorm partials: 64-pixel blocks of the stored output, ordered [image][phase][source block]
+    o = out.float()
+    ph = torch.stack([o[:, py::2, px::2, :].reshape(N, Hs * Ws // 64, 64, Cout) for py in range(2) for px in range(2)], 1)
+    ref_st = torch.stack([ph.sum(3), (ph * ph).sum(3)], -1).reshape(nblk, Cout, 2)
+    st_err = float((stats - ref_st).abs().max() / ref_st.abs().max())
+    assert st_err < 1e-5, f"fused GN statistics off by {st_err}"
+    got = G.from_nhwc(out)
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    direct = F.conv2d(F.interpolate(G.rounded(x, dtype).double(), scale_factor=2, mode="nearest"), w.double(), b.double(),
+                      padding=1).float()
+    e_direct = common.rel_l2(got, direct)
+    if dtype in (1, 2):
+        # 16-bit modes round the SUMMED weights: the tight check uses exactly the operands the kernel sees (rounded source,
+        # rounded phase weights, fp64 math); the direct form is then only off by that one weight rounding
+        w4r = G.rounded(w4, dtype).double().reshape(2, 2, Cout, 2, 2, C0 + C1)
+        xp = F.pad(G.rounded(x, dtype).double(), (1, 1, 1, 1))
+        ref = torch.zeros(N, Cout, 2 * Hs, 2 * Ws, dtype=torch.float64)
+        for py in range(2):
+            for px in range(2):
+                acc = b.double().view(1, -1, 1, 1).expand(N, Cout, Hs, Ws).clone()
+                for a in range(2):
+                    for bb in range(2):
+                        sl = xp[:, :, py + a:py + a + Hs, px + bb:px + bb + Ws]
+                        acc += torch.einsum("nchw,oc->nohw", sl, w4r[py, px, :, a, bb, :])
+                ref[:, :, py::2, px::2] = acc
+        e = common.rel_l2(got, ref.float())
+        assert e_direct < (4e-3 if dtype == 1 else 6e-4), f"{name}: vs upsample+conv {e_direct}"
+    else:
+        e = e_direct
+    G.report(f"conv_up/{name}/{G.DN[dtype]}", rel_l2=e, rel_l2_vs_direct=e_direct)
+    assert e < G.tol(dtype), f"{name}: rel_l2 {e}"
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_conv2d_output_and_statistics_do_not_depend_on_the_tile(dtype):
     """The tile of a launch is picked from the batch size; a sample's result must not depend on it (sample-parallel sharding:
