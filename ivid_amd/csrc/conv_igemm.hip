@@ -49,7 +49,10 @@ struct ConvArgs {
   float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+// UP4: the phase-decomposed "nearest x2 upsample + conv 3x3" form (taps == 4, ivid_conv3x3_up) -- a separate
+// instantiation, so that the plain convolution's issue path and epilogue carry none of its branches / index arithmetic
+// (a runtime switch cost the plain launches 3-8 %)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool UP4>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const ConvArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   int tn = tile - tm * p.ntiles_n;
   // taps == 4: the cout tiles of the four output phases (py, px) of one pixel tile are neighbours (shared A in L2)
   int phase = 0;
-  if (p.nt_phase) {
+  if constexpr (UP4) {
     phase = tn / p.nt_phase;
     tn -= phase * p.nt_phase;
   }
@@ -120,40 +123,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   // back, so they hit in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the whole channel extent of
   // the tile once per tap.  (The order must be a compile-time property: a runtime switch here made hipcc place an
   // s_waitcnt vmcnt(0) between the A and the B batch of global_load_lds, serialising the load latency.)
-  int ld_tap = 0, ld_ch = 0;  // K-step that the next issue() loads
-  auto issue = [&](int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + A_BYTES;
+  int ld_tap = 0, ld_ch = 0;  // K-step that the next issue loads
+  // The loads of a K-step in two parts: issue_prep() = the wave-uniform part (which tap / channel slab: scalar code, once
+  // per step), issue_piece(stage, j) = ONE 16-byte LDS-DMA piece per lane (j < A_IT: activation rows, else weight rows) --
+  // the 16-bit / fp32 main loop spreads the pieces between its MFMA groups so that their address arithmetic and issue
+  // cost run in the shadow of the matrix pipe instead of in front of it.
+  bool is_second = false;
+  int is_dy = 0, is_dx = 0, is_delta = 0;
+  size_t is_koff = 0;
+  auto issue_prep = [&]() {
     const int cbase = ld_ch * BKE;
-    const bool second = cbase >= p.C0;
-    const int Cs = second ? p.C1 : p.C0;
-    const int coff = second ? cbase - p.C0 : cbase;
-    int dy = 0, dx = 0;
-    if (p.taps == 9) {
-      dy = ld_tap / 3 - 1;
-      dx = ld_tap - (dy + 1) * 3 - 1;
-    } else if (p.taps == 4) {  // tap (a, b) of output phase (py, px) reads the source pixel at (py - 1 + a, px - 1 + b)
-      dy = py - 1 + (ld_tap >> 1);
-      dx = px - 1 + (ld_tap & 1);
+    is_second = cbase >= p.C0;
+    const int Cs = is_second ? p.C1 : p.C0;
+    const int coff = is_second ? cbase - p.C0 : cbase;
+    is_dy = 0;
+    is_dx = 0;
+    if constexpr (UP4) {  // tap (a, b) of output phase (py, px) reads the source pixel at (py - 1 + a, px - 1 + b)
+      is_dy = py - 1 + (ld_tap >> 1);
+      is_dx = px - 1 + (ld_tap & 1);
+    } else if (p.taps == 9) {
+      is_dy = ld_tap / 3 - 1;
+      is_dx = ld_tap - (is_dy + 1) * 3 - 1;
     }
-    const int delta = ((dy * p.W + dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const bool inb = (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
-      const char* g = (second ? a_base1[i] : a_base0[i]) + delta;
-      g = inb ? g : p.zero;
-      glds16(g, sA + (i * NT + wave * 64) * 16);
-    }
-    const size_t koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
-      glds16(g, sB + (i * NT + wave * 64) * 16);
-    }
+    is_delta = ((is_dy * p.W + is_dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
+    is_koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
     if (++ld_tap == p.taps) {
       ld_tap = 0;
       ++ld_ch;
     }
+  };
+  auto issue_piece = [&](int stage, int j) {
+    char* sA = smem + stage * STAGE;
+    if (j < A_IT) {
+      const int i = j;
+      const bool inb = (unsigned)(a_y[i] + is_dy) < (unsigned)p.H && (unsigned)(a_x[i] + is_dx) < (unsigned)p.W;
+      const char* g = (is_second ? a_base1[i] : a_base0[i]) + is_delta;
+      g = inb ? g : p.zero;
+      glds16(g, sA + (i * NT + wave * 64) * 16);
+    } else {
+      const int i = j - A_IT;
+      const char* g = b_ptr[i] ? b_ptr[i] + is_koff : p.zero;
+      glds16(g, sA + A_BYTES + (i * NT + wave * 64) * 16);
+    }
+  };
+  auto issue = [&](int stage) {
+    issue_prep();
+#pragma unroll
+    for (int j = 0; j < A_IT + B_IT; ++j) issue_piece(stage, j);
   };
 
   f32x16 acc[MI][NI];
@@ -231,16 +247,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
       }
     } else {
-    vec_t a[2][MI], b[2][NI];
-    load_frags(sA, sB, 0, a[0], b[0]);
-    if (kt + 1 < nk) issue((kt + 1) & 1);
+    // ONE fragment set that rotates: a fragment is re-requested for k-piece kk+1 right after its last MFMA of k-piece kk
+    // (n outer / m inner: the weight fragment of column block ni is free after the block, the activation fragments free up
+    // one by one during the last column block).  After every k-piece a quarter of the NEXT step's LDS-DMA pieces is issued:
+    // the MFMAs just issued keep the matrix pipe busy meanwhile.  The fences keep hipcc from re-clustering the pieces in
+    // front of the MFMAs (where both waves of a SIMD would sit in their issue code at the same time).
+    vec_t a[MI], b[NI];
+    load_frags(sA, sB, 0, a, b);
+    const bool more = kt + 1 < nk;
+    if (more) issue_prep();
+    constexpr int NP = A_IT + B_IT;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) load_frags(sA, sB, kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
+      const int piece = 2 * (kk + 1) + fhalf;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) MmaT<T>::run(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni]);
+        for (int mi = 0; mi < MI; ++mi) {
+          MmaT<T>::run(a[mi], b[ni], acc[mi][ni]);
+          if (kk < 3 && ni == NI - 1) a[mi] = *(const vec_t*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
+        }
+        if (kk < 3) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int j = kk * NP / 4; j < (kk + 1) * NP / 4; ++j) issue_piece((kt + 1) & 1, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     }
   }
@@ -363,7 +397,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
           const vec_t ov = f32_to_vec<T>(v);
           size_t mo = (size_t)m;
-          if (p.taps == 4) {  // source pixel (img, y, x) of phase (py, px) -> output pixel (2y + py, 2x + px) of the 2H x 2W image
+          if constexpr (UP4) {  // source pixel (img, y, x) of phase (py, px) -> output pixel (2y + py, 2x + px) of the 2H x 2W image
             const int img = m / HW, rem = m - img * HW;
             const int y = rem / p.W, x = rem - y * p.W;
             mo = ((size_t)img * (2 * p.H) + 2 * y + py) * (2 * p.W) + 2 * x + px;
@@ -396,7 +430,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
         const int wbase = m0 + wm * WTM + (mi / FL) * (FL * 32);  // first pixel of this block
         if (lr == 0 && wbase < p.M && n < Cout) {
           size_t slot = (size_t)(wbase / (FL * 32));
-          if (p.taps == 4) {  // blocks of the 2H x 2W output image: [image][phase][source block] (any partition of an image works)
+          if constexpr (UP4) {  // blocks of the 2H x 2W output image: [image][phase][source block] (any partition of an image works)
             const int bpi = HW / (FL * 32), img = (int)slot / bpi;
             slot = (size_t)img * (4 * bpi) + (size_t)phase * bpi + (slot - (size_t)img * bpi);
           }
@@ -426,7 +460,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool UP4 = false>
 int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   ConvArgs a = a0;
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -435,10 +469,10 @@ int launch_conv(const ConvArgs& a0, hipStream_t stream) {
   constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-  a.nt_phase = a.taps == 4 ? nt : 0;
-  a.ntiles_n = a.taps == 4 ? 4 * nt : nt;
+  a.nt_phase = UP4 ? nt : 0;
+  a.ntiles_n = UP4 ? 4 * nt : nt;
   a.ntiles_total = mt * a.ntiles_n;
-  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, UP4>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -512,6 +546,13 @@ static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int
   }
 #define IVID_CONV_DISPATCH(TT)                                             \
   do {                                                                     \
+    if (taps == 4) {                                                       \
+      if (tile_cfg == 2) return launch_conv<TT, 256, 256, 2, 4, true>(a, s); \
+      if (tile_cfg == 4) return launch_conv<TT, 512, 128, 8, 1, true>(a, s); \
+      if (tile_cfg == 5) return launch_conv<TT, 64, 128, 1, 2, true>(a, s);  \
+      if (tile_cfg == 6) return launch_conv<TT, 128, 384, 2, 4, true>(a, s); \
+      return launch_conv<TT, 128, 128, 2, 2, true>(a, s);                  \
+    }                                                                      \
     if (tile_cfg == 2) return launch_conv<TT, 256, 256, 2, 4>(a, s);       \
     if (tile_cfg == 3) return launch_conv<TT, 128, 32, 4, 1>(a, s);        \
     if (tile_cfg == 4) return launch_conv<TT, 512, 128, 8, 1>(a, s);       \
