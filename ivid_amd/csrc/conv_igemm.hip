@@ -123,54 +123,44 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   // back, so they hit in the XCD's L2 (tile working set ~50 KB) instead of re-streaming the whole channel extent of
   // the tile once per tap.  (The order must be a compile-time property: a runtime switch here made hipcc place an
   // s_waitcnt vmcnt(0) between the A and the B batch of global_load_lds, serialising the load latency.)
-  int ld_tap = 0, ld_ch = 0;  // K-step that the next issue loads
-  // The loads of a K-step in two parts: issue_prep() = the wave-uniform part (which tap / channel slab: scalar code, once
-  // per step), issue_piece(stage, j) = ONE 16-byte LDS-DMA piece per lane (j < A_IT: activation rows, else weight rows) --
-  // the 16-bit / fp32 main loop spreads the pieces between its MFMA groups so that their address arithmetic and issue
-  // cost run in the shadow of the matrix pipe instead of in front of it.
-  bool is_second = false;
-  int is_dy = 0, is_dx = 0, is_delta = 0;
-  size_t is_koff = 0;
-  auto issue_prep = [&]() {
+  int ld_tap = 0, ld_ch = 0;  // K-step that the next issue() loads
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + A_BYTES;
     const int cbase = ld_ch * BKE;
-    is_second = cbase >= p.C0;
-    const int Cs = is_second ? p.C1 : p.C0;
-    const int coff = is_second ? cbase - p.C0 : cbase;
-    is_dy = 0;
-    is_dx = 0;
+    const bool second = cbase >= p.C0;
+    const int Cs = second ? p.C1 : p.C0;
+    const int coff = second ? cbase - p.C0 : cbase;
+    int dy = 0, dx = 0;
     if constexpr (UP4) {  // tap (a, b) of output phase (py, px) reads the source pixel at (py - 1 + a, px - 1 + b)
-      is_dy = py - 1 + (ld_tap >> 1);
-      is_dx = px - 1 + (ld_tap & 1);
+      dy = py - 1 + (ld_tap >> 1);
+      dx = px - 1 + (ld_tap & 1);
     } else if (p.taps == 9) {
-      is_dy = ld_tap / 3 - 1;
-      is_dx = ld_tap - (is_dy + 1) * 3 - 1;
+      dy = ld_tap / 3 - 1;
+      dx = ld_tap - (dy + 1) * 3 - 1;
     }
-    is_delta = ((is_dy * p.W + is_dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
-    is_koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
+    const int delta = ((dy * p.W + dx) * Cs + coff) * (int)sizeof(T);  // wave-uniform, |delta| < 2^31
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool inb = (unsigned)(a_y[i] + dy) < (unsigned)p.H && (unsigned)(a_x[i] + dx) < (unsigned)p.W;
+      const char* g = (second ? a_base1[i] : a_base0[i]) + delta;
+      g = inb ? g : p.zero;
+      glds16(g, sA + (i * NT + wave * 64) * 16);
+    }
+    const size_t koff = ((size_t)ld_tap * Ctot + cbase) * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const char* g = b_ptr[i] ? b_ptr[i] + koff : p.zero;
+      glds16(g, sB + (i * NT + wave * 64) * 16);
+    }
     if (++ld_tap == p.taps) {
       ld_tap = 0;
       ++ld_ch;
     }
   };
-  auto issue_piece = [&](int stage, int j) {
-    char* sA = smem + stage * STAGE;
-    if (j < A_IT) {
-      const int i = j;
-      const bool inb = (unsigned)(a_y[i] + is_dy) < (unsigned)p.H && (unsigned)(a_x[i] + is_dx) < (unsigned)p.W;
-      const char* g = (is_second ? a_base1[i] : a_base0[i]) + is_delta;
-      g = inb ? g : p.zero;
-      glds16(g, sA + (i * NT + wave * 64) * 16);
-    } else {
-      const int i = j - A_IT;
-      const char* g = b_ptr[i] ? b_ptr[i] + is_koff : p.zero;
-      glds16(g, sA + A_BYTES + (i * NT + wave * 64) * 16);
-    }
-  };
-  auto issue = [&](int stage) {
-    issue_prep();
-#pragma unroll
-    for (int j = 0; j < A_IT + B_IT; ++j) issue_piece(stage, j);
-  };
+  // (Measured and dropped, round 2: spreading the eight LDS-DMA pieces of the next step between the MFMA groups of the
+  // current one, with a single rotating fragment set -- +4..5 % kernel time on every layer: a DMA issue among MFMAs costs
+  // more than it hides, and the two waves of a SIMD already overlap each other's issue block.)
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -247,34 +237,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           }
       }
     } else {
-    // ONE fragment set that rotates: a fragment is re-requested for k-piece kk+1 right after its last MFMA of k-piece kk
-    // (n outer / m inner: the weight fragment of column block ni is free after the block, the activation fragments free up
-    // one by one during the last column block).  After every k-piece a quarter of the NEXT step's LDS-DMA pieces is issued:
-    // the MFMAs just issued keep the matrix pipe busy meanwhile.  The fences keep hipcc from re-clustering the pieces in
-    // front of the MFMAs (where both waves of a SIMD would sit in their issue code at the same time).
-    vec_t a[MI], b[NI];
-    load_frags(sA, sB, 0, a, b);
-    const bool more = kt + 1 < nk;
-    if (more) issue_prep();
-    constexpr int NP = A_IT + B_IT;
+    vec_t a[2][MI], b[2][NI];
+    load_frags(sA, sB, 0, a[0], b[0]);
+    if (kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int piece = 2 * (kk + 1) + fhalf;
+      if (kk < 3) load_frags(sA, sB, kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          MmaT<T>::run(a[mi], b[ni], acc[mi][ni]);
-          if (kk < 3 && ni == NI - 1) a[mi] = *(const vec_t*)(sA + a_off[mi] + ((piece ^ a_sw[mi]) << 4));
-        }
-        if (kk < 3) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-#pragma unroll
-        for (int j = kk * NP / 4; j < (kk + 1) * NP / 4; ++j) issue_piece((kt + 1) & 1, j);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int ni = 0; ni < NI; ++ni) MmaT<T>::run(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni]);
     }
     }
   }
