@@ -11,7 +11,13 @@
 //   O^T[d][q] += V^T . P^T (A operand = V^T fragments, B operand = P straight from the S^T
 //          accumulators: the MFMA k index is (lane half, element), the same kv permutation is
 //          applied to the V^T fragment, so no cross-lane movement of P is needed.)
-// bf16 mode: v_mfma_f32_32x32x16_bf16; V is transposed into LDS as Vt[d][kv] while staging.
+// 16-bit modes: v_mfma_f32_32x32x16_{bf16,f16}.  K and V both arrive by LDS-DMA as [kv][d] rows (no register staging, no
+//           VALU); the V^T fragments of the P.V MFMA come out of gfx950's transpose read: ds_read_b64_tr_b16 hands lane i of
+//           a 16-lane group COLUMN i of the 4 x 16 halfword block whose row pieces the 16 lanes address (lane i: row i/4,
+//           columns 4 (i%4) .. +3; measured with scripts/micro/tr_probe.hip) -- i.e. four consecutive kv of one d, exactly
+//           half an MFMA fragment.  The V image swizzles its 16-byte pieces by ((row>>1)&1)<<2, which spreads the 32 lanes
+//           of a transpose read over all 64 banks.  (Round 1 transposed V with 16 ds_write_b16 per thread and tile and paid
+//           24 v_mov per tile to reassemble the fragments.)
 // fp32 mode: v_mfma_f32_32x32x2_f32 (exact); V stays [kv][d] (one float per lane per MFMA).
 #include "common.h"
 #include "internal.h"
@@ -65,6 +71,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const vec_t*)(base + (size_t)q * rowstride + (2 * kk + hf) * 16);
 
+  // transpose-read base of this lane inside the V tile (16-bit modes): row 4 hf + i/4, piece (2 g + (i%4)/2) ^ swizzle,
+  // 8-byte half (i%4)%2, with i = lane&15, g = (lane>>4)&1; the row's swizzle bit (row>>1)&1 = (i>>3)&1 is lane-constant
+  // because fragments add multiples of 8 rows; the d >= 32 half (dt = 1) is piece + 4, i.e. byte ^ 64
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+  const int tr_i = lane & 15;
+  const int vt_base0 = (4 * hf + (tr_i >> 2)) * RB + (((2 * ((lane >> 4) & 1) + ((tr_i & 3) >> 1)) ^ (((tr_i >> 3) & 1) << 2)) << 4) +
+                       (tr_i & 1) * 8;
+  const int vt_base1 = vt_base0 ^ 64;
+
   f32x16 o[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -73,43 +89,48 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
   float m_run = -1e30f, l_run = 0.f;
   const float sc = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e): scores in the log2 domain
 
+  // lane offsets of this thread's K / V pieces inside a 64-row tile (swizzled source piece, lane-linear LDS image)
+  unsigned k_voff[KPIECES / NT], v_voff[KPIECES / NT];
+#pragma unroll
+  for (int i = 0; i < KPIECES / NT; ++i) {
+    const int p = i * NT + tid;
+    const int row = p / PPR, pos = p - row * PPR;
+    k_voff[i] = (unsigned)((size_t)row * rowstride + HD * sizeof(T) + (pos ^ AttnCfg<T>::swz(row)) * 16);
+    v_voff[i] = (unsigned)((size_t)row * rowstride + 2 * HD * sizeof(T) + (IS_BF16 ? pos ^ (((row >> 1) & 1) << 2) : pos) * 16);
+  }
   for (int kv0 = 0; kv0 < T_; kv0 += KVB) {
     __syncthreads();  // previous tile fully consumed
     // ---- stage K: swizzled source, lane-linear LDS image ----
+    // (wave-uniform 64-bit tile base + the lane offsets computed once before the loop: no per-tile address arithmetic)
+    const char* const tile_base = base + (size_t)kv0 * rowstride;
 #pragma unroll
-    for (int i = 0; i < KPIECES / NT; ++i) {
-      const int p = i * NT + tid;
-      const int row = p / PPR, pos = p - row * PPR;
-      const int c = pos ^ AttnCfg<T>::swz(row);
-      glds16(base + (size_t)(kv0 + row) * rowstride + HD * sizeof(T) + c * 16, sK + (i * NT + wave * 64) * 16);
-    }
-    if constexpr (!IS_BF16) {
-      // ---- stage V as [kv][d] (fp32) ----
+    for (int i = 0; i < KPIECES / NT; ++i) glds16_s(tile_base, k_voff[i], sK + (i * NT + wave * 64) * 16);
+    // ---- stage V as [kv][d]: fp32 plain; 16-bit with the pieces of row r at position pos ^ (((r>>1)&1)<<2) ----
 #pragma unroll
-      for (int i = 0; i < KPIECES / NT; ++i) {
-        const int p = i * NT + tid;
-        const int row = p / PPR, pos = p - row * PPR;
-        glds16(base + (size_t)(kv0 + row) * rowstride + 2 * HD * sizeof(T) + pos * 16, sV + (i * NT + wave * 64) * 16);
-      }
-    } else {
-      // ---- stage V transposed: Vt[d][kv], 8-byte units XOR-swizzled by (d>>1)&15 ----
-#pragma unroll
-      for (int i = 0; i < KPIECES / NT; ++i) {
-        const int p = i * NT + tid;
-        const int kv = p / PPR, d0 = (p - kv * PPR) * 8;
-        const vec_t v = *(const vec_t*)(base + (size_t)(kv0 + kv) * rowstride + 2 * HD * sizeof(T) + d0 * 2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = d0 + e;
-          *(T*)(sV + d * 128 + (((kv >> 2) ^ ((d >> 1) & 15)) << 3) + (kv & 3) * 2) = v[e];
-        }
-      }
-    }
+    for (int i = 0; i < KPIECES / NT; ++i) glds16_s(tile_base, v_voff[i], sV + (i * NT + wave * 64) * 16);
     wait_vmcnt0();
     __syncthreads();
 
     // ---- S^T = K.Q^T for the two 32-row halves of the tile ----
     f32x16 s[2];
+    if constexpr (IS_BF16) {
+      // all eight K fragments are requested before the first MFMA (one LDS latency for the tile instead of one per MFMA)
+      vec_t kf[2][KK];
+#pragma unroll
+      for (int kvh = 0; kvh < 2; ++kvh) {
+        const int row = kvh * 32 + fq;
+        const int sw = AttnCfg<T>::swz(row);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[kvh][kk] = *(const vec_t*)(sK + row * RB + (((2 * kk + hf) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int kvh = 0; kvh < 2; ++kvh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kvh][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) MmaT<T>::run(kf[kvh][kk], qf[kk], s[kvh]);
+      }
+    } else {
 #pragma unroll
     for (int kvh = 0; kvh < 2; ++kvh) {
 #pragma unroll
@@ -119,13 +140,10 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         const vec_t kf = *(const vec_t*)(sK + row * RB + (((2 * kk + hf) ^ sw) << 4));
-        if constexpr (IS_BF16) {
-          MmaT<T>::run(kf, qf[kk], s[kvh]);
-        } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[kvh] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[kk][j], s[kvh], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) s[kvh] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[kk][j], s[kvh], 0, 0, 0);
       }
+    }
     }
     // ---- online softmax (per lane: one query, 32 of the 64 kv; lane^32 has the rest) ----
     float mt = -1e30f;
@@ -136,14 +154,21 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
     mt = fmaxf(mt, __shfl_xor(mt, 32)) * sc;  // sc > 0: the max of the scaled scores (log2 domain)
     const float m_new = fmaxf(m_run, mt);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float ps = 0.f;
+    // two scores per packed instruction (v_pk_fma_f32 for the exponent argument, v_pk_add_f32 for the row sum): the kernel is
+    // bound by VALU issue, not by the matrix pipe
+    f32x2 ps2 = {0.f, 0.f};
+    const f32x2 sc2 = {sc, sc}, mn2 = {-m_new, -m_new};
 #pragma unroll
     for (int kvh = 0; kvh < 2; ++kvh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[kvh][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kvh][r], sc, -m_new));  // scale folded into the exponent
-        ps += s[kvh][r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = f32x2{s[kvh][r], s[kvh][r + 1]} * sc2 + mn2;  // scale folded into the exponent
+        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        s[kvh][r] = e[0];
+        s[kvh][r + 1] = e[1];
+        ps2 = ps2 + e;
       }
+    float ps = ps2[0] + ps2[1];
     ps += __shfl_xor(ps, 32);
     l_run = l_run * alpha + ps;
     m_run = m_new;
@@ -163,20 +188,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void attn_kernel(const char* __restri
           vec_t pf;
 #pragma unroll
           for (int e = 0; e < 8; ++e) pf[e] = (T)s[kvh][8 * mm + e];
-          // element e of lane-half hf is kv = kvh*32 + 16*mm + 8*(e>>2) + 4*hf + (e&3)
-          const int u0 = (kvh * 32 + 16 * mm + 4 * hf) >> 2;  // 8-byte unit of e = 0..3; e = 4..7 is unit u0+2
+          // element e of lane-half hf is kv = kvh*32 + 16*mm + 8*(e>>2) + 4*hf + (e&3): two transpose reads, each four
+          // consecutive kv of this lane's d = dt*32 + fq (rows kvb + 4 hf + 0..3 and + 8)
+          const int kvb = kvh * 32 + 16 * mm;
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const int d = dt * 32 + fq;
-            const int sw = (d >> 1) & 15;
-            const t16x4 lo = *(const t16x4*)(sV + d * 128 + ((u0 ^ sw) << 3));
-            const t16x4 hi = *(const t16x4*)(sV + d * 128 + (((u0 + 2) ^ sw) << 3));
-            vec_t vf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              vf[e] = lo[e];
-              vf[4 + e] = hi[e];
-            }
+            const char* vb = sV + (dt ? vt_base1 : vt_base0) + kvb * RB;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + 8 * RB));
+            const vec_t vf = __builtin_bit_cast(vec_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             MmaT<T>::run(vf, pf, o[dt]);
           }
         }
