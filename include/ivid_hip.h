@@ -61,6 +61,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_SILU_F32 11       /* ivid_silu_f32 */
 #define IVID_OP_STEM_IM2COL 12    /* ivid_stem_im2col */
 #define IVID_OP_CONV3X3_UP 13     /* ivid_conv3x3_up */
+#define IVID_OP_COPY 14           /* ivid_copy */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -188,6 +189,11 @@ int ivid_embed_inputs(const int64_t* times, const int64_t* classes, int Bsrc, in
                       void* stream);
 /* y = silu(x) elementwise on fp32 (emb_layers[0] / time_embed[2], adm.py:175,360). */
 int ivid_silu_f32(const float* x, float* y, long long n, void* stream);
+/* Device copy as a kernel (bytes % 16 == 0, 16-byte aligned pointers).  The stacked classifier-free-guidance forward
+ * (classifier_free_guidance.py:39-42 = two backbone calls on the same x, t) shares what both halves of the batch have in
+ * common: until the first FiLM (adm.py:214-218) nothing depends on the class, so the first ResBlock's in_layers convolution
+ * is computed for one half and duplicated with this call. */
+int ivid_copy(void* dst, const void* src, long long bytes, void* stream);
 
 /* ---- model boundary layout changes ----
  * fp32 NCHW [Bsrc,Cin,H,W] -> NHWC dtype [N,H,W,Cpad] (zero padded channels, batch replicated n % Bsrc). */

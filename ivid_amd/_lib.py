@@ -67,6 +67,7 @@ SIGNATURES = {
     "ivid_attention": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "ivid_embed_inputs": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "ivid_silu_f32": (i32, [vp, vp, i64, vp]),
+    "ivid_copy": (i32, [vp, vp, i64, vp]),
     "ivid_nchw_to_nhwc": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_stem_im2col": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
@@ -86,7 +87,7 @@ SIGNATURES = {
 # op codes of the launch program (include/ivid_hip.h IVID_OP_*)
 OP_CODES = {"ivid_conv2d": 1, "ivid_conv3x3_gn": 2, "ivid_conv3x3_gn_skip": 3, "ivid_conv3x3_gn_out": 4, "ivid_gn_partial": 5,
             "ivid_gn_finalize": 6, "ivid_gn_finalize2": 7, "ivid_gn_apply": 8, "ivid_attention": 9, "ivid_embed_inputs": 10,
-            "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13}
+            "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13, "ivid_copy": 14}
 
 
 class Slot(C.Union):

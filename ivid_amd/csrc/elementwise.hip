@@ -182,6 +182,25 @@ extern "C" int ivid_embed_inputs(const int64_t* times, const int64_t* classes, i
   return ivid_check_launch("embed_inputs");
 }
 
+// 16 bytes per lane, grid-stride: a plain device copy that stays a kernel node of the forward's hipGraph
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n16) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+// Device copy of `bytes` (a multiple of 16, both pointers 16-byte aligned).  Used by the stacked classifier-free-guidance
+// forward: up to the first FiLM (adm.py:214-218) the conditional and the unconditional half of the batch see identical inputs
+// (same x, same t, no class dependence before the embedding is applied), so the first ResBlock's in_layers convolution runs on
+// one half and its output is duplicated (classifier_free_guidance.py:39-42 runs the backbone twice instead).
+extern "C" int ivid_copy(void* dst, const void* src, long long bytes, void* stream) {
+  if (bytes < 0 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16) return ivid_set_error("copy: 16-byte granularity", hipSuccess);
+  if (!bytes) return 0;
+  const long long n16 = bytes / 16;
+  long long blocks = (n16 + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, n16);
+  return ivid_check_launch("copy");
+}
+
 extern "C" int ivid_silu_f32(const float* x, float* y, long long n, void* stream) {
   hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   return ivid_check_launch("silu");

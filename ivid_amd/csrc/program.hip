@@ -63,6 +63,8 @@ int run_op(const Op& o, void* s) {
                                FP(10), s);
     case IVID_OP_SILU_F32:
       return ivid_silu_f32(CFP(0), FP(1), o.a[2].i, s);
+    case IVID_OP_COPY:
+      return ivid_copy(P(0), CP(1), o.a[2].i, s);
     case IVID_OP_STEM_IM2COL:
       return ivid_stem_im2col(I(0), CFP(1), I(2), I(3), I(4), I(5), I(6), I(7), P(8), s);
     default:

@@ -169,6 +169,10 @@ class UNetPlan:
         # in_layers conv of an `up` ResBlock as four 2x2 phase convolutions of the low-resolution tensor (4/9 of the
         # multiplications, csrc/conv_igemm.hip ivid_conv3x3_up) for sources up to this side; 0 disables it
         self.up4_max_side = int(os.environ.get("IVID_UP4_MAX_SIDE", "1024"))
+        # stacked CFG forward: what both halves of the batch have in common (everything in front of the first FiLM) is
+        # computed once and duplicated
+        self.share_cfg = os.environ.get("IVID_NO_CFG_SHARE", "0") != "1"
+        self._first_res_done = False
         self._sum_bias = {}
         self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
         self.taps = {}
@@ -333,6 +337,25 @@ class UNetPlan:
                       self.w[op.prefix + ".in_layers.2.weight_up4"].data_ptr(), self.w[op.prefix + ".in_layers.2.bias"].data_ptr(),
                       h1.ptr, n, x.side, x.side, op.cout, self.tile_cfg, h1.stats.data_ptr() if h1.stats is not None else None)
             self._free(act1)
+        elif fused and self.share_cfg and not self._first_res_done and self.n == 2 * self.bsrc and skip is None and not self.debug:
+            # First ResBlock of a stacked CFG forward (rows >= bsrc repeat x and t with the null class,
+            # classifier_free_guidance.py:39-42): the stem output and this block's in_layers (GroupNorm without FiLM, SiLU,
+            # conv) do not depend on the class, so rows bsrc.. would recompute rows 0..bsrc-1 bit for bit.  The convolution
+            # runs on the first half; its output and its GroupNorm partials are duplicated (image-major layouts: a half is
+            # one contiguous block).
+            half = self.bsrc
+            xh = _Act(x.buf, half, x.side, x.c, x.stats)
+            xh.stats_blk = x.stats_blk
+            h1h = _Act(h1.buf, half, so, op.cout, h1.stats)
+            ab1 = self._gn_coeffs(xh, None, op.prefix + ".in_layers.0", None)
+            self._conv3_gn(xh, None, ab1, False, op.prefix + ".in_layers.2", h1h, None, 0)
+            h1.stats_blk = h1h.stats_blk
+            self.arena.put(ab1)
+            nb = half * so * so * op.cout * self.esz
+            self._rec("ivid_copy", h1.ptr + nb, h1.ptr, nb)
+            if h1.stats is not None:
+                sb = half * (so * so // h1.stats_blk) * op.cout * 2 * 4
+                self._rec("ivid_copy", h1.stats.data_ptr() + sb, h1.stats.data_ptr(), sb)
         elif fused:
             ab1 = self._gn_coeffs(x, skip, op.prefix + ".in_layers.0", None)
             self._conv3_gn(x, skip, ab1, op.mode == "up", op.prefix + ".in_layers.2", h1, None, 0)
@@ -347,6 +370,7 @@ class UNetPlan:
         else:
             act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
             self._free(h1)
+        self._first_res_done = True
         out = self._new(n, so, op.cout, stats=True)
         kstep = 128 // self.esz
         if op.cout <= 128:

@@ -282,3 +282,11 @@ def test_launch_plan_builds_without_a_gpu_and_every_launch_matches_its_c_signatu
     for _fn, name, a in pl.launches:
         if name == "ivid_conv3x3_up":                    # source side, channels: the activated low-resolution tensor
             assert a[9] == a[10] and (a[9] * a[10]) % 64 == 0 and a[11] > 32
+    # stacked CFG forward (2 x 2 rows here): the class-independent in_layers convolution of the first ResBlock runs on one
+    # half of the batch (N = 2) and is duplicated (output + GroupNorm partials) whenever that layer takes the fused kernel
+    first_fused = next(a for _fn, name, a in pl.launches if name in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip", "ivid_conv2d")
+                       and name != "ivid_conv2d" or (name == "ivid_conv2d" and a[15] == 9))
+    shared = cnt["ivid_copy"] == 2
+    assert cnt["ivid_copy"] in (0, 2)
+    if cfg == "LARGE128" or precision == "bf16":
+        assert shared and first_fused[12] == 2 and pl.n == 4, (cnt["ivid_copy"], first_fused[12])
