@@ -512,7 +512,7 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         if fsr is not None:   # the chain uncond -> warp/inpaint views -> SR stays on the GPU (inference/sample.py of this package)
             torch.cuda.synchronize(dev)
             q0 = time.perf_counter()
-            hi = [super_resolve(fsr, smp, classes=classes[i], steps=sr_steps, strength=3.0, batchsize=16) for i, (smp, _) in enumerate(out)]
+            hi = [super_resolve(fsr, smp, classes=classes[i], steps=sr_steps, strength=3.0, batchsize=nviews) for i, (smp, _) in enumerate(out)]   # all views of a sample in one batch (bs 27: +3.5 % per view over 16 + 11)
             torch.cuda.synchronize(dev)
             sr_seconds[0] = time.perf_counter() - q0
             assert all(torch.isfinite(h).all() for h in hi)
@@ -525,7 +525,7 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         torch.cuda.synchronize(dev)
     run_short(fu, fc, seeds, views if a.config == "c3" else views[:2], classes, bs, sample_all)   # warm-up: plans, hipGraphs (no 1000-step chain)
     if fsr is not None:
-        super_resolve(fsr, torch.randn(nviews, 4, 128, 128, device=dev).clamp(-1, 1), classes=1, steps=2, strength=3.0, batchsize=16)
+        super_resolve(fsr, torch.randn(nviews, 4, 128, 128, device=dev).clamp(-1, 1), classes=1, steps=2, strength=3.0, batchsize=nviews)
     fence()
     warp_s.update(conditions=0.0, add_view=0.0, calls=0)
     t0 = time.perf_counter()
