@@ -134,6 +134,7 @@ def phase_weights(w):
 UP_CASES = [
     # name, N, Hs, Ws, C0, C1, Cout, tile_cfg
     ("up_8to16_tile128", 2, 8, 8, 128, 0, 128, 1),
+    ("up_8to16_mtail_cout_tail", 3, 8, 8, 64, 0, 72, 1),        # M = 192: the second 128-row tile is half empty; Cout tail
     ("up_16to32_auto_c384", 2, 16, 16, 64, 0, 384, 0),
     ("up_16to32_bigtile_mtail", 3, 16, 16, 128, 0, 320, 2),
     ("up_nonsquare_concat", 1, 8, 16, 64, 64, 192, 5),
