@@ -175,6 +175,7 @@ class UNetPlan:
         self._first_res_done = False
         self._sum_bias = {}
         self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
+        self._tile_up4 = int(os.environ.get("IVID_TILE_UP4", "0"))   # tuning hook: tile of the phase-form up-convolutions
         self.taps = {}
         self.dtype = weights.dtype
         self.esz = _lib.esz(self.dtype)
@@ -335,7 +336,8 @@ class UNetPlan:
             h1.stats_blk = 64
             self._rec("ivid_conv3x3_up", self.dtype, act1.ptr, op.cin, None, 0,
                       self.w[op.prefix + ".in_layers.2.weight_up4"].data_ptr(), self.w[op.prefix + ".in_layers.2.bias"].data_ptr(),
-                      h1.ptr, n, x.side, x.side, op.cout, self.tile_cfg, h1.stats.data_ptr() if h1.stats is not None else None)
+                      h1.ptr, n, x.side, x.side, op.cout, self.tile_cfg or self._tile_up4,
+                      h1.stats.data_ptr() if h1.stats is not None else None)
             self._free(act1)
         elif fused and self.share_cfg and not self._first_res_done and self.n == 2 * self.bsrc and skip is None and not self.debug:
             # First ResBlock of a stacked CFG forward (rows >= bsrc repeat x and t with the null class,
