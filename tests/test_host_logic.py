@@ -290,3 +290,36 @@ def test_launch_plan_builds_without_a_gpu_and_every_launch_matches_its_c_signatu
     assert cnt["ivid_copy"] in (0, 2)
     if cfg == "LARGE128" or precision == "bf16":
         assert shared and first_fused[12] == 2 and pl.n == 4, (cnt["ivid_copy"], first_fused[12])
+
+
+def test_bench_flop_accounting_adds_up_to_the_reference_count(monkeypatch):
+    """bench.py prices every recorded launch with the reference's FLOP count (2 x MACs; the phase-form up-convolution at its
+    9-tap count).  Summed over a planned forward of the large model this must reproduce BASELINE's 613.78 GFLOP per
+    sample-forward -- minus the one convolution the stacked CFG forward shares between its halves."""
+    import importlib.util
+    from ivid_amd import _lib
+    from ivid_amd.diffusion.backbones import plan as P
+    from ivid_amd.diffusion.backbones.spec import build_spec
+
+    class FakeStream:
+        def __init__(self, device=None):
+            self.cuda_stream = 0
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setenv("IVID_PY_LAUNCH", "1")
+    spec_b = importlib.util.spec_from_file_location("ivid_bench", os.path.join(C.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_b)
+    spec_b.loader.exec_module(bench)
+    spec = build_spec(**C.LARGE128)
+    sd = {k: torch.zeros(s) for k, s in C.schema_for(C.LARGE128)}
+    bsrc = 2
+    pl = P.UNetPlan(spec, P.PackedWeights(spec, sd, "meta", _lib.BF16), "meta", bsrc, True)
+    prof = [(name, a, 1.0) for _fn, name, a in pl.launches]
+    fam, _other = bench.kernel_table(prof, "bf16")
+    launched = sum(f["flop"] for f in fam.values())
+    first = next(op for op in spec.res_ops())
+    shared = 2.0 * bsrc * first.res_out ** 2 * first.cout * 9 * first.cin       # the half that is copied instead of computed
+    ref = pl.n * bench.GFLOP_PER_SAMPLE_FWD["large"] * 1e9
+    assert abs((launched + shared) / ref - 1.0) < 5e-3, (launched + shared) / ref
+    up = sum(bench.up_flops(a) for name, a, _ in prof if name == "ivid_conv3x3_up")
+    executed = (launched - up * 5.0 / 9.0) / ref
+    assert 0.92 < executed < 0.95, executed
