@@ -365,6 +365,9 @@ def main():
         # `value` / `job_tflops` count the REFERENCE's work (2 x MACs of every layer of every forward).  Two exact rewrites make
         # the kernels execute less: Upsample2d + conv3x3 as four 2x2 phase convolutions (ivid_conv3x3_up: 4/9 of the MACs) and
         # the stacked CFG forward computing its class-independent first convolution once for both halves of the batch.
+        for e in entries:
+            if e["kernel"] == "conv_igemm_kernel" and any(name == "ivid_conv3x3_up" for name, _, _ in prof):
+                e["note"] = "includes the phase-form up-convolutions (ivid_conv3x3_up) at their 9-tap algorithmic count; 4/9 of those MACs are executed"
         ref_flop = plan.n * gflop * 1e9
         launched = sum(f["flop"] for f in fam.values())                 # as launched: the shared convolution counts once
         up_alg = sum(up_flops(args) for name, args, _ in prof if name == "ivid_conv3x3_up")
