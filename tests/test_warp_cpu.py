@@ -1,5 +1,8 @@
 """CPU: the warp oracle against the reference-generated mesh fixtures, Pillow, and its own geometry."""
+import os
+
 import numpy as np
+import pytest
 from PIL import Image
 
 import common as C
@@ -148,3 +151,22 @@ def test_oracle_simple_render_and_unpadded_mesh_embedding():
     assert ok.mean() > 0.3                                    # all but discontinuity triangles (alpha 0; plenty at S = 16)
     assert np.abs(centre[ok] - g["depth_lin_16"][..., 0][ok]).max() < 2e-3
     assert out["depth"].max() > 150.0                         # the unpadded mesh leaves a rim of background (clear depth -> far)
+
+
+GL_TAGS = [s[0] for s in WC.gl_scenes()]
+
+
+@pytest.mark.parametrize("tag", GL_TAGS)
+def test_oracle_render_equals_the_references_renderer_on_real_opengl(tag):
+    """tests/golden/warp_gl.npz holds what the REFERENCE's AggregationRenderer.render / aggregate_conditions return when their
+    own code and GLSL shaders run on real OpenGL (Mesa llvmpipe; tests/golden/make_golden_gl.py).  The C rasteriser +
+    aggregation + resolve of the oracle must reproduce it: this pins the warp oracle -- against which the HIP kernels are
+    checked at every size -- to an actual OpenGL implementation.  Scenes: two views, three views with two depth layers, the
+    full `3x9` viewset (26 source views), a camera inside the scene (512 triangles clipped at the near plane), white-noise
+    depth (everything low-confidence), an SSAA-5 free-view frame, and a full-size 128^2 pair at 384^2."""
+    g = C.load_golden("warp_gl")
+    tag_, S, ssaa, near, far, views, target = next(s for s in WC.gl_scenes() if s[0] == tag)
+    meshes, cols = zip(*[WC.oracle_mesh(WC.synthetic_rgbd(S, seed, layers=layers)[0], mv) for mv, seed, layers in views])
+    o = W.render(list(meshes), list(cols), target, 45, S, S * ssaa, near=near, far=far)
+    rr = W.resolve({k: o[k] for k in ("color", "depth", "mask_color", "mask_depth")}, S, ssaa, 0.6, 5.0, 0.03, 0.03, 3) if ssaa == 3 else None
+    WC.gl_assert(WC.gl_compare(g, tag, near, o, rr))

@@ -414,3 +414,32 @@ def test_compat_functions_keep_reference_signatures():
     assert out.color.shape == (S, S, 3) and out.mask.shape == (S, S, 1) and set(out.keys()) == {"color", "depth", "mask", "mask_rgb", "depth_convex"}
     with pytest.raises(ValueError):
         rr.render([dict(mesh, faces=mesh.faces[::-1])], [col], WC.orbit(0.0, 0.0))   # not a triangulate()-ordered height field
+
+
+@pytest.mark.parametrize("tag", [s[0] for s in WC.gl_scenes()])
+def test_product_warp_equals_the_references_renderer_on_real_opengl(tag):
+    """The product's whole warp path through the reference's own call forms -- depth_to_mesh (ivid_mesh_build),
+    AggregationRenderer.render (z-buffer + aggregation kernels), aggregate_conditions (resolve kernels) -- against what the
+    REFERENCE's code and GLSL shaders produce on real OpenGL (tests/golden/warp_gl.npz, made by tests/golden/make_golden_gl.py
+    on Mesa llvmpipe).  Same bars as the CPU test that pins the oracle to those vectors."""
+    from ivid_amd import rgbd_3d
+    from ivid_amd.rgbd_3d import utils as U
+    g = C.load_golden("warp_gl")
+    _tag, S, ssaa, near, far, views, target = next(s for s in WC.gl_scenes() if s[0] == tag)
+    meshes, cols = [], []
+    for mv, seed, layers in views:
+        hw = WC.synthetic_rgbd(S, seed, layers=layers)[0].transpose(1, 2, 0) * 0.5 + 0.5
+        depth_lin = U.linearize_depth(hw[:, :, 3:], 0.6, 5.0)                         # sample.py:128-139
+        mesh = U.depth_to_mesh(depth_lin, padding="frustum", fov=45, modelview=mv, atol=0.03, rtol=0.03, erode_rgb=3, cal_normal=True)
+        mesh.modelview = mv
+        meshes.append(mesh)
+        cols.append(np.ascontiguousarray(hw[:, :, :3]))
+    rend = rgbd_3d.AggregationRenderer(S * ssaa, S, near=near, far=far, device=0, max_views=max(27, len(views)))
+    hi = rend.render(meshes, cols, target, 45)
+    cond = None
+    if ssaa == 3:
+        cond = U.aggregate_conditions(rend, meshes, cols, target, fov=45, near=0.6, far=5, atol=0.03, rtol=0.03, erode_rgb=3)
+    e = WC.gl_compare(g, tag, near, hi, cond)
+    G.report(f"warp/vs_opengl_{tag}", **e)
+    print("vs OpenGL", tag, e)
+    WC.gl_assert(e)
