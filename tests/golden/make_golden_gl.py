@@ -108,3 +108,25 @@ for tag, S, ssaa, near, far, views, target in WC.gl_scenes():
     del rend
 np.savez_compressed(os.path.join(HERE, "warp_gl.npz"), gl_version=np.array(info["GL_VERSION"]), gl_renderer=np.array(info["GL_RENDERER"]), **out)
 print("wrote warp_gl.npz", round(os.path.getsize(os.path.join(HERE, "warp_gl.npz")) / 1e6, 2), "MB")
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SimpleRenderer + forward_backward_warp (training-time augmentation, utils.py:335-417) on the real renderer: the same two
+# cases as tests/golden/warp_fbw.npz (which runs the same reference function on the oracle rasteriser)
+fbw = {}
+for tag, S, seed, yaw, pitch in [("S32", 32, 31, 0.2, -0.1), ("S64", 64, 32, -0.25, 0.12)]:
+    hw = WC.synthetic_rgbd(S, seed, smooth_color=True)[0].transpose(1, 2, 0) * 0.5 + 0.5       # [S,S,4] in [0,1]
+    mv0, mv1 = WC.orbit(0.0, 0.0), WC.orbit(yaw, pitch)
+    rend = ref_r.SimpleRenderer(3 * S, S, near=0.1, far=200.0, device=0)
+    o = ref_u.forward_backward_warp(rend, hw.astype(np.float64), glm.mat4(mv1), glm.mat4(mv0), padding=S, fov=45, near=0.6, far=5.0,
+                                    atol=0.02, rtol=0.02)
+    for k in ("color", "depth", "mask"):
+        fbw[f"{tag}_{k}"] = np.asarray(o[k], np.float32)
+    # one plain SimpleRenderer.render as well (the forward half: view 0's mesh seen from view 1)
+    mesh0 = ref_u.depth_to_mesh(ref_u.linearize_depth(hw[:, :, 3:], 0.6, 5.0), padding=S, fov=45, modelview=glm.mat4(mv0), atol=None, rtol=None)
+    res = rend.render(mesh0, hw[:, :, :3], glm.mat4(mv1), 45)
+    for k in ("color", "depth", "mask"):
+        fbw[f"{tag}_fwd_{k}"] = np.asarray(res[k]).astype(np.bool_ if k == "mask" else np.float32)
+    print(f"forward_backward_warp {tag}: mask {o.mask.mean():.3f}; forward render coverage {res.mask.mean():.3f}")
+    del rend
+np.savez_compressed(os.path.join(HERE, "warp_gl_fbw.npz"), **fbw)
+print("wrote warp_gl_fbw.npz", round(os.path.getsize(os.path.join(HERE, "warp_gl_fbw.npz")) / 1e6, 2), "MB")

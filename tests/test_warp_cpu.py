@@ -170,3 +170,18 @@ def test_oracle_render_equals_the_references_renderer_on_real_opengl(tag):
     o = W.render(list(meshes), list(cols), target, 45, S, S * ssaa, near=near, far=far)
     rr = W.resolve({k: o[k] for k in ("color", "depth", "mask_color", "mask_depth")}, S, ssaa, 0.6, 5.0, 0.03, 0.03, 3) if ssaa == 3 else None
     WC.gl_assert(WC.gl_compare(g, tag, near, o, rr))
+
+
+def test_oracle_simple_renderer_and_forward_backward_warp_equal_real_opengl():
+    """tests/golden/warp_gl_fbw.npz = the reference's forward_backward_warp + SimpleRenderer.render executed with their own
+    code and shaders on real OpenGL (make_golden_gl.py).  warp_fbw.npz -- the same reference function run on the ORACLE
+    rasteriser (simple_render), the fixture the product is checked against -- must equal the OpenGL run: masks identical,
+    colours identical, depth to 1e-5.  (The plain forward render of the real SimpleRenderer is compared with the product on
+    the GPU: test_warp_gpu.py.)"""
+    g, b = C.load_golden("warp_gl_fbw"), C.load_golden("warp_fbw")
+    for tag, S, seed in (("S32", 32, 31), ("S64", 64, 32)):
+        m, rm = g[f"{tag}_mask"][..., 0] > 0, b[f"{tag}_mask"][..., 0] > 0
+        assert (m ^ rm).sum() <= 2 and 0.3 < m.mean() < 0.95
+        both = m & rm
+        assert np.abs(g[f"{tag}_depth"][..., 0][both] - b[f"{tag}_depth"][..., 0][both]).max() < 1e-5
+        assert (np.abs(g[f"{tag}_color"][both] - b[f"{tag}_color"][both]).max(-1) > 1.5 / 255).mean() < 2e-3

@@ -443,3 +443,34 @@ def test_product_warp_equals_the_references_renderer_on_real_opengl(tag):
     G.report(f"warp/vs_opengl_{tag}", **e)
     print("vs OpenGL", tag, e)
     WC.gl_assert(e)
+
+
+def test_simple_renderer_and_forward_backward_warp_equal_real_opengl():
+    """tests/golden/warp_gl_fbw.npz: the reference's SimpleRenderer.render and forward_backward_warp executed with their own
+    code and shaders on real OpenGL (make_golden_gl.py).  The product's rgbd_3d.SimpleRenderer (HIP z-buffer kernel) and
+    forward_backward_warp must reproduce them."""
+    from ivid_amd import rgbd_3d
+    from ivid_amd.rgbd_3d import utils as U
+    g, b = C.load_golden("warp_gl_fbw"), C.load_golden("warp_fbw")
+    for tag, S in (("S32", 32), ("S64", 64)):
+        hw, mv0, mv1 = b[f"{tag}_rgbd"], WC.orbit(0.0, 0.0), b[f"{tag}_mv1"]
+        r = rgbd_3d.SimpleRenderer(3 * S, S, near=0.1, far=200, device=0)
+        # the forward half: view 0's mesh (numeric padding S, no discontinuity test, utils.py:374-383) seen from view 1
+        mesh0 = U.depth_to_mesh(U.linearize_depth(hw[:, :, 3:], 0.6, 5.0), padding=S, fov=45, modelview=mv0, atol=None, rtol=None)
+        res = r.render(mesh0, hw[:, :, :3], mv1, 45)
+        gm, om = g[f"{tag}_fwd_mask"][..., 0], np.asarray(res.mask)[..., 0] > 0
+        bb = gm & om
+        rel = np.abs(g[f"{tag}_fwd_depth"][..., 0][bb] - np.asarray(res.depth)[..., 0][bb]) / g[f"{tag}_fwd_depth"][..., 0][bb]
+        coff = float((np.abs(g[f"{tag}_fwd_color"][bb] - np.asarray(res.color)[bb]).max(-1) > 1e-3).mean())
+        out = U.forward_backward_warp(r, hw, mv1, mv0, padding=S, fov=45, near=0.6, far=5.0, atol=0.02, rtol=0.02)
+        m, rm = out.mask[..., 0] > 0, g[f"{tag}_mask"][..., 0] > 0
+        both = m & rm
+        de = np.abs(out.depth[..., 0][both] - g[f"{tag}_depth"][..., 0][both])
+        ce = np.abs(out.color[both] - g[f"{tag}_color"][both]).max(-1)
+        e = dict(fwd_mask_mismatch=int((gm ^ om).sum()), fwd_depth_rel_p999=float(np.quantile(rel, 0.999)), fwd_color_off_frac=coff,
+                 mask_mismatch=int((m ^ rm).sum()), pixels=int(m.size), depth_p99=float(np.quantile(de, 0.99)),
+                 color_p99=float(np.quantile(ce, 0.99)))
+        G.report(f"warp/vs_opengl_forward_backward_{tag}", **e)
+        print("vs OpenGL fbw", tag, e)
+        assert e["fwd_mask_mismatch"] <= 2 and e["fwd_depth_rel_p999"] < 2e-4 and e["fwd_color_off_frac"] < 2e-3, e
+        assert e["mask_mismatch"] <= max(4, e["pixels"] // 100) and e["depth_p99"] < 5e-3 and e["color_p99"] < 0.05, e
