@@ -13,9 +13,12 @@ Pinning status
   * aggregate_conditions' post-processing of the rendered buffers (8-bit LANCZOS, centre-sample depth, 7-of-9
     masks, depth_edge, erosion): PINNED — tests/golden/make_golden_warp.py runs the reference's own
     aggregate_conditions on a stub renderer that returns stored hi-res buffers (tests/golden/warp_resolve.npz).
-  * rasterisation + shader arithmetic: PARITY UNPINNED — the reference renders with OpenGL through
-    moderngl/EGL, none of which exists offline; oracle/warp_raster.c restates the GL rules (near-plane
-    clipping, top-left fill rule, perspective-correct varyings) in a formulation different from the HIP kernel.
+  * rasterisation + shader arithmetic: PINNED TO REAL OPENGL — moderngl / EGL do not exist offline, but Mesa's software
+    rasteriser does: oracle/glshim/ (an off-screen llvmpipe context through the swrast DRI driver + a stand-in `moderngl`
+    module) lets tests/golden/make_golden_gl.py run the reference's own rgbd_3d/moderngl_renderer.py and GLSL shaders;
+    tests/test_warp_cpu.py checks this restatement (oracle/warp_raster.c: near-plane clipping, top-left fill rule,
+    perspective-correct varyings, in a formulation different from the HIP kernel) against those outputs
+    (tests/golden/warp_gl.npz, warp_gl_fbw.npz): 7 scenes, 0 mask pixels off, depth to the 24-bit z resolution.
 Missing third-party pieces restated here: PyGLM lookAt/perspective/inverse (GLM's documented
 formulas, float32 like glm.mat4), cv2.erode (min filter whose border never erodes).
 """

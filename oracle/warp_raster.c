@@ -3,11 +3,12 @@
  * CPU restatement of what the reference delegates to OpenGL (rgbd_3d/moderngl_renderer.py:198-202,
  * 307-315 and rgbd_3d/shaders/aggregation.{vsh,fsh,csh}): each source mesh is drawn ALONE with a
  * `<` depth test into a 24-bit depth buffer, fragments are shaded with the view-angle weight, and
- * the views are blended per pixel.  PARITY UNPINNED: no OpenGL/EGL exists in the build container, so
- * this follows the GL 4.3 rasterisation rules (near-plane clipping of primitives in clip space, pixel
- * centres, top-left fill rule, perspective-correct smooth varyings, window-space-linear depth,
- * gl_FrontFacing from the signed window area, NEAREST texel fetch) rather than outputs of the
- * reference itself.
+ * the views are blended per pixel.  It follows the GL 4.3 rasterisation rules (near-plane clipping of
+ * primitives in clip space, pixel centres, top-left fill rule, perspective-correct smooth varyings,
+ * window-space-linear depth, gl_FrontFacing from the signed window area, NEAREST texel fetch) and is
+ * PINNED TO REAL OPENGL: tests/golden/make_golden_gl.py runs the reference's own renderer + shaders on
+ * Mesa llvmpipe (oracle/glshim/) and tests/test_warp_cpu.py compares this rasteriser with those outputs
+ * (7 scenes incl. the 26-view `3x9` viewset and near-plane clipping: no mask pixel differs).
  *
  * Deliberately formulated differently from the HIP kernel (ivid_amd/csrc/warp.hip evaluates 2-D
  * homogeneous edge functions and never clips): here a triangle is CLIPPED against the near plane

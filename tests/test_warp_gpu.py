@@ -1,6 +1,7 @@
-"""GPU parity of the HIP depth-warp path: mesh build vs the reference-generated fixture (pinned), rasterise +
-aggregate vs the C software rasteriser (GL rules restated — unpinned, compared by coverage IoU / tolerances as
-SURVEY.md §7 hard part 7 prescribes), SSAA resolve vs Pillow / the numpy restatement (bit-exact)."""
+"""GPU parity of the HIP depth-warp path: mesh build vs the reference-generated fixture (pinned), rasterise + aggregate
+vs (i) what the reference's own renderer and GLSL shaders produce on real OpenGL (tests/golden/warp_gl*.npz, Mesa llvmpipe
+through oracle/glshim) and (ii) the C software rasteriser of the oracle -- itself pinned to those vectors -- at sizes and
+batch shapes the fixtures do not hold; SSAA resolve vs Pillow / the numpy restatement (bit-exact)."""
 import numpy as np
 import pytest
 import torch
