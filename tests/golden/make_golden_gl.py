@@ -130,3 +130,46 @@ for tag, S, seed, yaw, pitch in [("S32", 32, 31, 0.2, -0.1), ("S64", 64, 32, -0.
     del rend
 np.savez_compressed(os.path.join(HERE, "warp_gl_fbw.npz"), **fbw)
 print("wrote warp_gl_fbw.npz", round(os.path.getsize(os.path.join(HERE, "warp_gl_fbw.npz")) / 1e6, 2), "MB")
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two more call patterns of the reference (stored separately: tests/golden/warp_gl_more.npz)
+more = {}
+# (1) free-view fusion rendering (inference/render.py:40-88): load_scene's meshes -- NUMERIC padding 32, metric depth
+#     (inference/utils.py:108-111) -- on an SSAA-5 renderer with near 0.1 / far 200
+S = 32
+views = [(WC.orbit(0.0, 0.0), 90, False), (WC.orbit(0.3, 0.1), 91, True)]
+target = WC.orbit(0.6 * np.cos(2.0), 0.15 * np.sin(2.0))
+meshes, cols = [], []
+for v, (mv, seed, layers) in enumerate(views):
+    hw = WC.synthetic_rgbd(S, seed, layers=layers)[0].transpose(1, 2, 0) * 0.5 + 0.5
+    depth_lin = ref_u.linearize_depth(hw[:, :, 3:], 0.6, 5.0).astype(np.float32)
+    mesh = ref_u.depth_to_mesh(depth_lin, 32, 45, glm.mat4(mv), atol=0.03, rtol=0.03, erode_rgb=3, cal_normal=True)
+    mesh.modelview = glm.mat4(mv)
+    meshes.append(mesh)
+    cols.append(np.ascontiguousarray(hw[:, :, :3]))
+    more[f"pad32/vbo_{v}"] = np.concatenate([mesh.vertices.position, mesh.vertices.normal, mesh.vertices.uv, mesh.vertices.flag], -1).astype(np.float32)
+    more[f"pad32/faces_{v}"] = mesh.faces.astype(np.int32)
+rend = ref_r.AggregationRenderer(5 * S, S, near=0.1, far=200.0, device=0)
+hi = rend.render(meshes, cols, glm.mat4(target), 45)
+for k in ("color", "depth", "mask_color", "mask_depth"):
+    more[f"pad32/{k}"] = np.asarray(hi[k]).astype(np.float32 if k in ("color", "depth") else np.bool_)
+more["pad32/target"] = target
+print(f"free view on load_scene meshes: coverage {hi.mask_depth.mean():.3f}")
+del rend
+# (2) the autoregressive chain of inference/sample.py:87-139: ONE renderer, aggregate_conditions(is_autoregressive=True) before
+#     every new view -- only the newest mesh is uploaded per call, the earlier ones persist in the renderer
+vs = WC.viewset_3x9()
+rend = ref_r.AggregationRenderer(3 * S, S, near=0.01, far=200.0, device=0, max_views=27)
+meshes, cols = [], []
+for k in range(5):
+    mv = WC.orbit(*vs[k])
+    if k > 0:
+        cond = ref_u.aggregate_conditions(rend, meshes, cols, glm.mat4(mv), fov=45, near=0.6, far=5, atol=0.03, rtol=0.03, erode_rgb=3)
+        for key in ("color", "depth", "mask", "mask_rgb", "depth_convex"):
+            more[f"chain/{k}/{key}"] = np.asarray(cond[key]).astype(np.float32 if key in ("color", "depth", "depth_convex") else np.bool_)
+        print(f"chain view {k}: mask {cond.mask.mean():.3f} mask_rgb {cond.mask_rgb.mean():.3f}")
+    mesh, col = ref_mesh(WC.synthetic_rgbd(S, 200 + k, layers=(k == 2))[0], mv)
+    meshes.append(mesh)
+    cols.append(col)
+np.savez_compressed(os.path.join(HERE, "warp_gl_more.npz"), **more)
+print("wrote warp_gl_more.npz", round(os.path.getsize(os.path.join(HERE, "warp_gl_more.npz")) / 1e6, 2), "MB")

@@ -185,3 +185,35 @@ def test_oracle_simple_renderer_and_forward_backward_warp_equal_real_opengl():
         both = m & rm
         assert np.abs(g[f"{tag}_depth"][..., 0][both] - b[f"{tag}_depth"][..., 0][both]).max() < 1e-5
         assert (np.abs(g[f"{tag}_color"][both] - b[f"{tag}_color"][both]).max(-1) > 1.5 / 255).mean() < 2e-3
+
+
+def _edict_mesh(vbo, faces, mv):
+    """A reference-layout mesh (what depth_to_mesh returns) from a stored vertex buffer [n, 9] + faces."""
+    return dict(vertices=dict(position=vbo[:, :3], normal=vbo[:, 3:6], uv=vbo[:, 6:8], flag=vbo[:, 8:9]), faces=faces, modelview=mv)
+
+
+def test_oracle_equals_real_opengl_on_load_scene_meshes_and_along_the_autoregressive_chain():
+    """tests/golden/warp_gl_more.npz (make_golden_gl.py, the reference's code on real OpenGL): (1) free-view fusion rendering
+    (inference/render.py) of load_scene's meshes -- numeric padding 32 -- at SSAA 5; (2) the conditions of views 1..4 of a
+    `3x9` chain produced by ONE renderer with aggregate_conditions(is_autoregressive=True) (inference/sample.py:87-139)."""
+    g = C.load_golden("warp_gl_more")
+    S = 32
+    views = [(WC.orbit(0.0, 0.0), 90, False), (WC.orbit(0.3, 0.1), 91, True)]
+    meshes = [W.from_reference_mesh(_edict_mesh(g[f"pad32/vbo_{v}"], g[f"pad32/faces_{v}"], views[v][0]), S) for v in range(2)]
+    cols = [np.ascontiguousarray(WC.synthetic_rgbd(S, seed, layers=layers)[0].transpose(1, 2, 0)[:, :, :3] * 0.5 + 0.5) for _, seed, layers in views]
+    o = W.render(meshes, cols, g["pad32/target"], 45, S, 5 * S, near=0.1, far=200.0)
+    WC.gl_assert(WC.gl_compare({k.replace("pad32/", "x/"): v for k, v in g.items()}, "x", 0.1, o))
+    vs = WC.viewset_3x9()
+    ms, cs = [], []
+    for k in range(5):
+        mv = WC.orbit(*vs[k])
+        if k > 0:
+            hi = W.render(ms, cs, mv, 45, S, 3 * S)
+            rr = W.resolve({q: hi[q] for q in ("color", "depth", "mask_color", "mask_depth")}, S, 3, 0.6, 5.0, 0.03, 0.03, 3)
+            assert (g[f"chain/{k}/mask"] != rr["mask"]).sum() <= 2 and (g[f"chain/{k}/mask_rgb"] != rr["mask_rgb"]).sum() <= 2, k
+            assert (np.abs(g[f"chain/{k}/depth"] - rr["depth"]) > 1e-3).sum() <= 2, k
+            assert (np.abs(g[f"chain/{k}/depth_convex"] - rr["depth_convex"]) > 1e-3).sum() <= 2, k
+            assert (np.abs(g[f"chain/{k}/color"] - rr["color"]) > 1.5 / 255).mean() < 5e-3, k
+        m, c = WC.oracle_mesh(WC.synthetic_rgbd(S, 200 + k, layers=(k == 2))[0], mv)
+        ms.append(m)
+        cs.append(c)

@@ -475,3 +475,53 @@ def test_simple_renderer_and_forward_backward_warp_equal_real_opengl():
         print("vs OpenGL fbw", tag, e)
         assert e["fwd_mask_mismatch"] <= 2 and e["fwd_depth_rel_p999"] < 2e-4 and e["fwd_color_off_frac"] < 2e-3, e
         assert e["mask_mismatch"] <= max(4, e["pixels"] // 100) and e["depth_p99"] < 5e-3 and e["color_p99"] < 0.05, e
+
+
+def test_product_equals_real_opengl_on_load_scene_meshes_and_along_the_autoregressive_chain():
+    """tests/golden/warp_gl_more.npz (the reference's code on real OpenGL).  (1) inference/render.py's case: load_scene's
+    meshes (depth_to_mesh with numeric padding 32, built here by the product) on an SSAA-5 renderer with near 0.1 / far 200;
+    the mesh itself is compared with the stored reference mesh too.  (2) inference/sample.py:87-139: ONE product renderer,
+    aggregate_conditions before every new view -- only the newest mesh is uploaded per call (is_autoregressive), the
+    earlier ones persist in the renderer."""
+    from ivid_amd import rgbd_3d
+    from ivid_amd.rgbd_3d import utils as U
+    g = C.load_golden("warp_gl_more")
+    S = 32
+    views = [(WC.orbit(0.0, 0.0), 90, False), (WC.orbit(0.3, 0.1), 91, True)]
+    meshes, cols = [], []
+    for v, (mv, seed, layers) in enumerate(views):
+        hw = WC.synthetic_rgbd(S, seed, layers=layers)[0].transpose(1, 2, 0) * 0.5 + 0.5
+        mesh = U.depth_to_mesh(U.linearize_depth(hw[:, :, 3:], 0.6, 5.0).astype(np.float32), 32, 45, mv, atol=0.03, rtol=0.03, erode_rgb=3,
+                               cal_normal=True)
+        vb = np.concatenate([mesh.vertices.position, mesh.vertices.normal, mesh.vertices.uv, mesh.vertices.flag], -1)
+        assert np.array_equal(mesh.faces, g[f"pad32/faces_{v}"]) and np.array_equal(vb[:, 8], g[f"pad32/vbo_{v}"][:, 8])
+        assert np.abs(vb[:, :3] - g[f"pad32/vbo_{v}"][:, :3]).max() < 2e-5 and np.abs(vb - g[f"pad32/vbo_{v}"]).max() < 2e-4
+        mesh.modelview = mv
+        meshes.append(mesh)
+        cols.append(np.ascontiguousarray(hw[:, :, :3]))
+    rend = rgbd_3d.AggregationRenderer(5 * S, S, near=0.1, far=200, device=0)
+    hi = rend.render(meshes, cols, g["pad32/target"], 45)
+    e = WC.gl_compare({k.replace("pad32/", "x/"): v for k, v in g.items()}, "x", 0.1, hi)
+    G.report("warp/vs_opengl_load_scene_ssaa5", **e)
+    print("vs OpenGL load_scene", e)
+    WC.gl_assert(e)
+    vs = WC.viewset_3x9()
+    rend = rgbd_3d.AggregationRenderer(3 * S, S, near=0.01, far=200, device=0, max_views=27)
+    ms, cs = [], []
+    for k in range(5):
+        mv = WC.orbit(*vs[k])
+        if k > 0:
+            c = U.aggregate_conditions(rend, ms, cs, mv, fov=45, near=0.6, far=5, atol=0.03, rtol=0.03, erode_rgb=3)
+            ek = dict(mask=int((g[f"chain/{k}/mask"] != c.mask.astype(bool)).sum()), mask_rgb=int((g[f"chain/{k}/mask_rgb"] != c.mask_rgb.astype(bool)).sum()),
+                      depth_off=int((np.abs(g[f"chain/{k}/depth"] - c.depth) > 1e-3).sum()),
+                      convex_off=int((np.abs(g[f"chain/{k}/depth_convex"] - c.depth_convex) > 1e-3).sum()),
+                      color_off_frac=float((np.abs(g[f"chain/{k}/color"] - c.color) > 1.5 / 255).mean()))
+            G.report(f"warp/vs_opengl_chain_view{k}", **ek)
+            print("vs OpenGL chain", k, ek)
+            assert ek["mask"] <= 2 and ek["mask_rgb"] <= 2 and ek["depth_off"] <= 2 and ek["convex_off"] <= 2 and ek["color_off_frac"] < 5e-3, (k, ek)
+        hw = WC.synthetic_rgbd(S, 200 + k, layers=(k == 2))[0].transpose(1, 2, 0) * 0.5 + 0.5
+        mesh = U.depth_to_mesh(U.linearize_depth(hw[:, :, 3:], 0.6, 5.0), padding="frustum", fov=45, modelview=mv, atol=0.03, rtol=0.03,
+                               erode_rgb=3, cal_normal=True)
+        mesh.modelview = mv
+        ms.append(mesh)
+        cs.append(np.ascontiguousarray(hw[:, :, :3]))
