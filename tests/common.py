@@ -38,6 +38,9 @@ SR256 = dict(image_size=256, in_channels=8, out_channels=4, model_channels=128, 
              has_null_class=True, channel_mult=[1, 1, 2, 3, 4], attention_resolutions=[64, 32, 16], num_groups=32,
              num_heads=None, num_head_channels=64, dropout=0.0, use_fp16=False)
 MINI_SR = dict(MINI, image_size=64, in_channels=8, attention_resolutions=[32, 16])
+# the mini model at the reference sample_all's hard-wired 128 x 128 (inference/sample.py:50,68), attention at the 32^2 level
+MINI128 = dict(MINI, image_size=128, attention_resolutions=[32])
+MINI128_COND = dict(MINI128, in_channels=10)
 
 
 def schema_for(args):
