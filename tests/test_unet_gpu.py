@@ -353,3 +353,23 @@ def test_edge_batches_empty_and_single():
     got = m(x.cuda(), t.cuda(), cls.cuda()).cpu()
     ref = adm_oracle.unet_forward(sd, C.MINI, x, t, cls)
     assert C.rel_l2(got, ref) < PARITY_BAR
+
+
+@pytest.mark.parametrize("name,args,seed,batch", [("mini_fwd", C.MINI, 0, 2), ("mini_cond_fwd", C.MINI_COND, 2, 2),
+                                                  ("small128_fwd", C.SMALL128, 3, 1), ("large128_fwd", C.LARGE128, 4, 1)])
+def test_fp16_mode_against_the_references_own_fp16_torso(name, args, seed, batch):
+    """tests/golden/fwd_fp16_ref.npz: the reference model built with `use_fp16: true` (its fp16 torso, adm.py:508-516,
+    backbones/utils.py:6-13 -- what five of the six shipped configs select) run on the host (make_golden_fp16.py).  The
+    product's `fp16` precision (fp16 storage + fp16 MFMA operands, fp32 accumulate / GroupNorm / softmax) is an independent
+    fp16 computation of the same network: it must sit as close to the reference's fp16 output as two fp16 evaluations of one
+    function do (each is ~1.1-1.5e-3 from the fp32 result), and no farther from the fp32 output than the reference's own
+    fp16 torso is."""
+    m, _ = build(args, seed, "fp16")
+    g, x, t, cls = fwd_inputs(name, args, seed, batch)
+    ref16 = torch.from_numpy(C.load_golden("fwd_fp16_ref")[name])
+    out = m(x.cuda(), t.cuda(), cls.cuda() if cls is not None else None).cpu()
+    e16, e32, r16_32 = C.rel_l2(out, ref16), C.rel_l2(out, g["eps"]), C.rel_l2(ref16, g["eps"])
+    G.report(f"unet/{name}/fp16_vs_reference_fp16", rel_l2_vs_reference_fp16=e16, rel_l2_vs_reference_fp32=e32,
+             reference_fp16_vs_its_fp32=r16_32)
+    print("fp16 vs reference fp16", name, e16, e32, r16_32)
+    assert e16 < 3e-3 and e32 < 1.3 * r16_32 + 2e-4, (e16, e32, r16_32)
