@@ -78,3 +78,45 @@ def test_ddpm_chain_matches_reference_golden():
     out = sampler_oracle.ddpm_sample(lambda x, t: adm_oracle.unet_forward(sd, C.MINI_UNCLASS, x, t, None),
                                      torch.from_numpy(g["x_T"]), sampler_oracle.linear_betas(100))
     assert C.rel_l2(out["samples"], g["samples"]) < 1e-5
+
+
+def test_oracle_chain_matches_the_references_own_sample_all():
+    """tests/golden/sample_all_ref.npz: the reference's `sample_all` itself (inference/sample.py:30-147), run end to end in the
+    build container incl. its renderer on real OpenGL (tests/golden/make_golden_sample_all.py).  The oracle's pieces --
+    UNet, CFG / InpaintCFG, DDIM, depth_to_mesh, C rasteriser + aggregation + resolve -- chained with the reference's wiring
+    (sample.py:99-120) and fed the same seeded noise stream (the draw order of the reference) must reproduce its three views
+    and its conditioning tensors.  The product is checked against the same file on the GPU (tests/test_pipeline_gpu.py)."""
+    import warp_common as WC
+    from oracle import warp_oracle as W
+    g = C.load_golden("sample_all_ref")
+    S, near, far, atol, rtol = 128, 0.6, 5.0, 0.03, 0.03
+    su, sc, erode = (int(v) for v in g["cfg"])
+    guid, cls = float(g["guidance"]), torch.from_numpy(g["classes"])
+    vs = WC.viewset_3x9()
+    views = [WC.orbit(*vs[int(k)]) for k in g["view_ids"]]
+    sdu, sdc = C.synth_weights(C.MINI128, 0), C.synth_weights(C.MINI128_COND, 2)
+    uu = lambda x, t, c: adm_oracle.unet_forward(sdu, C.MINI128, x, t, c)
+    uc = lambda x, t, c: adm_oracle.unet_forward(sdc, C.MINI128_COND, x, t, c)
+    betas = sampler_oracle.linear_betas(1000)
+    torch.manual_seed(int(g["noise_seed"]))        # the default generator now yields the stream the reference drew from
+    x_T = torch.randn(1, 4, S, S)
+    prev = [sampler_oracle.ddim_sample(lambda x, t: sampler_oracle.cfg_eps(uu, x, t, cls, guid), x_T, su, betas)["samples"]]
+    assert C.rel_l2(prev[0][0], g["samples"][0]) < 1e-5
+    for j in (1, 2):
+        meshes, cols = [], []
+        for k in range(j):
+            hw = prev[k][0].numpy().transpose(1, 2, 0) * 0.5 + 0.5                       # sample.py:83
+            meshes.append(W.depth_to_mesh(W.linearize_depth(hw[:, :, 3:], near, far), 45, views[k], atol, rtol, erode))
+            cols.append(np.ascontiguousarray(hw[:, :, :3]))
+        c = W.aggregate_conditions(meshes, cols, views[j], S, 3, 45, near, far, atol, rtol, erode)
+        T = lambda k: torch.from_numpy(np.asarray(c[k], np.float32)).permute(2, 0, 1)[None]
+        color, depth, mask, mask_rgb, convex = T("color") * 2 - 1, T("depth") * 2 - 1, T("mask"), T("mask_rgb"), T("depth_convex") * 2 - 1
+        dc = (color[0] - torch.from_numpy(g["cond_color"][j - 1])).abs().amax(0)
+        dd = (depth[0] - torch.from_numpy(g["cond_depth"][j - 1])).abs().amax(0)
+        assert (dc < 2.1 / 255).float().mean() > 0.999 and (dd < 1e-3).float().mean() > 0.999, (j, float((dc < 2.1 / 255).float().mean()))
+        y = torch.cat([color, depth], dim=1)
+        x2 = torch.randn(1, 4, S, S)                                                     # ddim.py:151: the conditional chain's x_T
+        res = sampler_oracle.ddim_sample(lambda x, t: sampler_oracle.inpaint_cfg_eps(uc, x, t, y, mask, cls, guid, mask_rgb), x2, sc, betas,
+                                         replace_rgb=(0.1, color, mask_rgb), replace_depth=(0.2, depth, mask), constrain_depth=(0.5, convex))
+        prev.append(res["samples"])
+        assert C.rel_l2(prev[j][0], g["samples"][j]) < 1e-3, (j, C.rel_l2(prev[j][0], g["samples"][j]))
