@@ -38,10 +38,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
 # flops (its 3 MFMAs per product are overhead, not work)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
-DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2}
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
@@ -161,10 +161,30 @@ KERNEL_OF = {"ivid_conv3x3_gn": "conv3x3_fused_kernel", "ivid_conv3x3_gn_skip": 
              "ivid_conv2d": "conv_igemm_kernel", "ivid_conv3x3_up": "conv_igemm_kernel", "ivid_attention": "attn_kernel", "ivid_conv3x3_gn_out": "conv3x3_out_kernel"}
 
 
+def canonical_launch(name, args):
+    """A `_c` launch (compensated storage: lo planes, include/ivid_hip.h ivid_conv2d_c) -> (base entry point, its argument
+    tuple, extra algorithmic bytes of the lo planes it reads / writes)."""
+    if name == "ivid_conv2d_c":
+        (dt, _s0, _c0, _s1, _c1, _w, _b, _o, olo, _r, rlo, rm, _om, n, h, w, cout, _t, _tc, _st) = args
+        plane = n * h * w * cout * ESZ[dt]
+        extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
+        return "ivid_conv2d", tuple(a for i, a in enumerate(args) if i not in (8, 10)), float(extra)
+    if name == "ivid_conv3x3_gn_skip_c":
+        dt, rm, n, h, w, cout = args[0], args[13], args[14], args[15], args[16], args[17]
+        plane = n * h * w * cout * ESZ[dt]
+        extra = (plane if args[10] else 0) + (0 if not args[12] else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
+        return "ivid_conv3x3_gn_skip", tuple(a for i, a in enumerate(args) if i not in (10, 12)), float(extra)
+    if name == "ivid_conv3x3_gn_out_c":
+        (dt, src, slo, c, ab, w, _wlo, b, o, n, h, w_, co) = args
+        return "ivid_conv3x3_gn_out", (dt, src, c, ab, w, b, o, n, h, w_, co), float(n * h * w_ * c * ESZ[dt] if slo else 0)
+    return name, args, 0.0
+
+
 def kernel_table(prof, precision):
     """[(c_abi_name, args, ms)] of one eager forward -> per-kernel {ms, launches, flop, bytes} and the ms of everything else."""
     fam, other = {}, {}
     for name, args, ms in prof:
+        name, args, lo_bytes = canonical_launch(name, args)
         k = KERNEL_OF.get(name)
         if k is None:
             other[name] = other.get(name, 0.0) + ms
@@ -172,6 +192,7 @@ def kernel_table(prof, precision):
         f = fam.setdefault(k, dict(ms=0.0, n=0, flop=0.0, byt=0.0))
         f["ms"] += ms
         f["n"] += 1
+        f["byt"] += lo_bytes
         if name == "ivid_conv2d":
             fl, _ = conv_flops(args)
             f["flop"] += fl
@@ -386,7 +407,7 @@ def main():
         # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
         # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
         # profiles/r01_mfma_power.txt) -- the ceiling this kernel actually works under:
-        if a.precision in ("bf16", "fp16") and dom["bound"] == "mfma":
+        if a.precision in ("bf16", "fp16", "fp16c") and dom["bound"] == "mfma":
             dom["power_limited_mfma_peak_random_operands"] = 1606.0
             dom["frac_of_power_limited_peak"] = round(dom["achieved"] / 1606.0, 4)
         result["roofline"] = dom
@@ -397,6 +418,8 @@ def main():
         if os.environ.get("IVID_BENCH_LAYERS"):  # per-launch table for kernel tuning (not part of the bench line)
             rows = []
             for name, args, ms in prof:
+                cname = name
+                name, args, _lo = canonical_launch(name, args)
                 if name == "ivid_conv2d":
                     fl, _ = conv_flops(args)
                     rows.append(dict(n=args[11], h=args[12], cin=args[2] + args[4], cout=args[14], taps=args[15],
@@ -410,8 +433,10 @@ def main():
                     rows.append(dict(fused=1, n=args[12], h=args[13], cin=args[2] + args[4], cout=args[15], taps=9, up=args[6],
                                      res=args[11], skip=(args[18] + args[20]) if len(args) > 17 else 0, ms=round(ms, 4),
                                      tflops=round(fl / ms / 1e9, 1)))
-                elif name in ("ivid_gn_apply", "ivid_gn_partial", "ivid_attention", "ivid_conv3x3_gn_out", "ivid_gn_finalize2"):
-                    rows.append(dict(op=name, args=[v for v in args if isinstance(v, int) and v < (1 << 32)], ms=round(ms, 4)))
+                else:
+                    rows.append(dict(op=cname, args=[v for v in args if isinstance(v, int) and v < (1 << 32)], ms=round(ms, 4)))
+                if cname != name:
+                    rows[-1]["lo_planes"] = 1
             with open(os.environ["IVID_BENCH_LAYERS"], "w") as f:
                 json.dump(rows, f, indent=0)
         result["forward_ms_eager_events"] = round(total_ms, 3)

@@ -62,6 +62,11 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_STEM_IM2COL 12    /* ivid_stem_im2col */
 #define IVID_OP_CONV3X3_UP 13     /* ivid_conv3x3_up */
 #define IVID_OP_COPY 14           /* ivid_copy */
+#define IVID_OP_CONV2D_C 15       /* ivid_conv2d_c */
+#define IVID_OP_CONV3X3_GN_SKIP_C 16 /* ivid_conv3x3_gn_skip_c */
+#define IVID_OP_GN_APPLY_C 17     /* ivid_gn_apply_c */
+#define IVID_OP_CONV3X3_GN_OUT_C 18 /* ivid_conv3x3_gn_out_c */
+#define IVID_OP_STEM_IM2COL_SPLIT 19 /* ivid_stem_im2col_split */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -107,6 +112,20 @@ int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1, int C1, c
 
 int ivid_conv2d_stats_block(int N, int H, int W, int Cout, int tile_cfg);
 
+/* ---- compensated 16-bit storage (precision mode "fp16c": IVID_F16 kernels + lo planes) ----
+ * The reference's arithmetic on its benchmark config is fp32 (configs/rgbd_imagenet_adm_128_large_cfg.json:18 `use_fp16: false`,
+ * adm.py:557 `h = x.type(self.dtype)`); a plain fp16 torso ends 1.07e-3 from it, a third of which is the ROUNDING OF THE
+ * RESIDUAL TRUNK at every block (`return self.skip_connection(x) + h`, adm.py:222; `(x + h)`, adm.py:286).  In this mode a trunk
+ * tensor is stored as TWO 16-bit NHWC planes: hi = T(v) and lo = T(v - float(hi)) of the fp32 value v (22 mantissa bits
+ * together).  MFMA operands read the hi plane alone -- it is exactly the rounded operand an fp16 MFMA would be fed anyway --
+ * while residual adds (below), GroupNorm-apply (ivid_gn_apply_c) and the output head (ivid_conv3x3_gn_out_c) read hi + lo.
+ * GroupNorm partial statistics of a tensor with a lo plane describe hi + lo.
+ *   out_lo : NULL or the lo plane of `out` (same shape);  res_lo : NULL or the lo plane of `res` (any res_mode).
+ * 16-bit dtypes, out_mode 0 only; everything else as ivid_conv2d. */
+int ivid_conv2d_c(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias,
+                  void* out, void* out_lo, const void* res, const void* res_lo, int res_mode, int out_mode, int N, int H, int W,
+                  int Cout, int taps, int tile_cfg, float* stats, void* stream);
+
 /* ---- Upsample2d (nearest x2) + Conv2d 3x3 of an `up` ResBlock's in_layers (adm.py:70-83 `F.interpolate(..., mode="nearest")`,
  *      adm.py:203-206 `h = in_rest(x); h = self.h_upd(h); h = in_conv(h)`) without the upsampled tensor ----
  * out[n, 2y+py, 2x+px, co] = bias[co] + sum_{a,b in {0,1}} sum_c cat(src0,src1)[n, y+py-1+a, x+px-1+b, c] * weight4[py*2+px][co][a*2+b][c]
@@ -141,6 +160,12 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
                          int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
                          const void* skip_weight, void* stream);
 
+/* ivid_conv3x3_gn_skip with the lo planes of the output / residual source (see ivid_conv2d_c); Cout > 128 only. */
+int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                           const void* weight, const float* bias, void* out, void* out_lo, const void* res, const void* res_lo,
+                           int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0, int skipC0,
+                           const void* skip1, int skipC1, const void* skip_weight, void* stream);
+
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].
  *   src NHWC [N,H,W,C] in `dtype`; ab fp32 [N][C][2]; weight [Cout][9][C] in `dtype`; 1 <= Cout <= 16; W % 32 == 0, H % 8 == 0.
@@ -148,6 +173,14 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
  * Reads the 1 GiB input once instead of three times (gn_apply round trip + nine shifted re-reads). */
 int ivid_conv3x3_gn_out(int dtype, const void* src, int C, const float* ab, const void* weight, const float* bias, float* out,
                         int N, int H, int W, int Cout, void* stream);
+
+/* The head in split form (16-bit dtypes): weight_lo = T(w - float(T(w))) in the layout of `weight`; the activated values are
+ * split into hi + lo parts while the halo is staged and every product is three MFMAs (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi), i.e.
+ * the layer is evaluated to ~2^-21: its operand roundings reach the model output unaveraged (7 % of the fp16 error budget,
+ * tests/tools/error_budget.py) and it has 0.05 % of the FLOPs.  src_lo: NULL or the lo plane of src (see ivid_conv2d_c).
+ * weight_lo NULL = ivid_conv3x3_gn_out. */
+int ivid_conv3x3_gn_out_c(int dtype, const void* src, const void* src_lo, int C, const float* ab, const void* weight,
+                          const void* weight_lo, const float* bias, float* out, int N, int H, int W, int Cout, void* stream);
 
 /* ---- GroupNorm32 + SiLU + FiLM (adm.py:36-41,159,175-180,214-218) ----
  * Step 1: per-(n, pixel-chunk, channel) partial sums of x and x^2 over cat(src0,src1) (NHWC).
@@ -173,6 +206,10 @@ int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, const float* 
  *   H, W are the SOURCE spatial dims.  out: NHWC dtype [N,Ho,Wo,C0+C1] (concat materialised here). */
 int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, void* out, int N,
                   int H, int W, int resample, int act, void* stream);
+
+/* Same with the lo planes of the two sources (see ivid_conv2d_c; NULL = none): x = hi + lo.  `out` is a plain tensor. */
+int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1,
+                    const float* ab, void* out, int N, int H, int W, int resample, int act, void* stream);
 
 /* ---- QKVAttention (adm.py:233-253), legacy per-head [q|k|v] channel interleave ----
  * qkv: NHWC [N,T,3*C] with channel = head*192 + {0..63 q, 64..127 k, 128..191 v}; out: [N,T,C], channel = head*64+d.
@@ -205,6 +242,13 @@ int ivid_nchw_to_nhwc(int dtype, const float* x, int Bsrc, int N, int Cin, int H
  *   x fp32 NCHW [Bsrc,Cin,H,W]; row n reads source n % Bsrc (the stacked CFG batch);  out [N,H,W,Kpad] in `dtype`. */
 int ivid_stem_im2col(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
                      void* stream);
+
+/* The stem in split form (16-bit dtypes, precision mode fp16c): the K row holds three segments of 9*Cin values
+ * [x_hi | x_lo | x_hi] (x_hi = T(x), x_lo = T(x - x_hi)), zeros behind; with weight rows [w_hi | w_hi | w_lo] in the same k order
+ * ivid_conv2d(taps = 1, C0 = Kpad) accumulates x_hi*w_hi + x_lo*w_hi + x_hi*w_lo: the stem to ~2^-21 (its two operand
+ * roundings were 9 % of the fp16 error budget) for two more K-steps of the model's cheapest layer.  Kpad >= 27*Cin. */
+int ivid_stem_im2col_split(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
+                           void* stream);
 
 /* ---- samplers (fp32 NCHW [B,4,H,W]) ----
  * eps = (1+s)*eps_c - s*eps_u (classifier_free_guidance.py:39-42); eps_u may be NULL (s ignored). */

@@ -11,7 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IVID_HIP_LIB") or os.path.join(_HERE, "lib", "libivid_hip.so")   # override: A/B tuning builds
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3   # include/ivid_hip.h IVID_*
-PRECISIONS = {"fp32": F32, "bf16": BF16, "fp16": F16, "bf16x3": BF16X3}
+# "fp16c": the fp16 kernels with COMPENSATED storage -- the residual trunk is kept as two fp16 planes hi + lo (22 mantissa
+# bits), stem and output head are evaluated in split form (include/ivid_hip.h ivid_conv2d_c)
+PRECISIONS = {"fp32": F32, "bf16": BF16, "fp16": F16, "bf16x3": BF16X3, "fp16c": F16}
+COMPENSATED = {"fp16c"}
 
 
 def esz(dtype):
@@ -54,6 +57,12 @@ SIGNATURES = {
     "ivid_unet_forward": (i32, [vp, vp, vp, vp, vp, i32, vp]),
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
+    "ivid_conv2d_c": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_conv3x3_gn_skip_c": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp,
+                                     vp, i32, vp, i32, vp, vp]),
+    "ivid_conv3x3_gn_out_c": (i32, [i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ivid_gn_apply_c": (i32, [i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ivid_stem_im2col_split": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_up": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn_out": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -87,7 +96,8 @@ SIGNATURES = {
 # op codes of the launch program (include/ivid_hip.h IVID_OP_*)
 OP_CODES = {"ivid_conv2d": 1, "ivid_conv3x3_gn": 2, "ivid_conv3x3_gn_skip": 3, "ivid_conv3x3_gn_out": 4, "ivid_gn_partial": 5,
             "ivid_gn_finalize": 6, "ivid_gn_finalize2": 7, "ivid_gn_apply": 8, "ivid_attention": 9, "ivid_embed_inputs": 10,
-            "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13, "ivid_copy": 14}
+            "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13, "ivid_copy": 14, "ivid_conv2d_c": 15,
+            "ivid_conv3x3_gn_skip_c": 16, "ivid_gn_apply_c": 17, "ivid_conv3x3_gn_out_c": 18, "ivid_stem_im2col_split": 19}
 
 
 class Slot(C.Union):

@@ -54,6 +54,10 @@ struct FusedArgs {
   const char* sk1;
   const char* skw;     // [Cout][skC0+skC1]
   int skC0, skC1;
+  // compensated 16-bit storage (precision mode fp16c, see conv_igemm.hip ConvArgs): optional lo planes of the output and
+  // of the residual source; only the LO instantiation of the kernel looks at them
+  char* out_lo;
+  const char* res_lo;
 #ifdef IVID_DEV_TIMELINE
   unsigned long long* dbg;             // [blocks][8] phase time stamps (scripts/dev/fused_timeline.py)
 #endif
@@ -83,7 +87,7 @@ constexpr int PIECES = (HROWS + 63) / 64;  // halo pieces per thread (64 halo pi
 constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 163,456 of the CU's 163,840
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <typename T>
+template <typename T, bool LO = false>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -589,6 +593,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
   // (fp32 storage: 8 pieces per lane and fragment -- batching four fragments would spill, so those modes prefetch per fragment)
   constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
   vec_t rres[HB][NPS];
+  vec_t rres_lo[LO ? HB : 1][LO ? NPS : 1];
+  const bool res_has_lo = LO && p.res_lo != nullptr;
+  const bool out_has_lo = LO && p.out_lo != nullptr;
   auto load_res = [&](int mi) {
     const int y = y0 + wm * 4 + mi;
 #pragma unroll
@@ -597,6 +604,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
       const size_t pix = p.res_mode == 1 ? ((size_t)img * p.H + y) * p.W + xr
                                          : ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (xr >> 1);
       rres[mi % HB][ps] = *(const vec_t*)(p.res + (pix * Cout + nbase + lc) * sizeof(T));
+      if constexpr (LO) {
+        if (res_has_lo) rres_lo[mi % HB][ps] = *(const vec_t*)(p.res_lo + (pix * Cout + nbase + lc) * sizeof(T));
+      }
     }
   };
   const bool res12 = (p.res_mode == 1 || p.res_mode == 2) && nbase + lc < Cout;
@@ -652,6 +662,14 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
         if (p.res_mode == 1 || p.res_mode == 2) {
           float rv[VE];
           vec_to_f32<T>(rres[mi % HB][ps], rv);
+          if constexpr (LO) {
+            if (res_has_lo) {
+              float rl[VE];
+              vec_to_f32<T>(rres_lo[mi % HB][ps], rl);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) rv[e] += rl[e];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += rv[e];
         } else if (p.res_mode == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)
@@ -665,15 +683,34 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
             vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
 #pragma unroll
             for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
+            if constexpr (LO) {
+              if (res_has_lo) {
+                vec_to_f32<T>(*(const vec_t*)(p.res_lo + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
+              }
+            }
           }
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
         }
         const vec_t ov = f32_to_vec<T>(v);
         *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+        float sv[VE];
+        vec_to_f32<T>(ov, sv);
+        if constexpr (LO) {
+          if (out_has_lo) {   // lo plane: what the 16-bit rounding dropped; the statistics describe hi + lo
+            float lv[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) lv[e] = v[e] - sv[e];
+            const vec_t ol = f32_to_vec<T>(lv);
+            *(vec_t*)(p.out_lo + (m * Cout + n) * sizeof(T)) = ol;
+            vec_to_f32<T>(ol, lv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) sv[e] += lv[e];
+          }
+        }
         if (p.stats) {
-          float sv[VE];
-          vec_to_f32<T>(ov, sv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             st_s[e] += sv[e];
@@ -711,8 +748,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 #endif
 }
 
-template <typename T> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T>;
+template <typename T, bool LO = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T, LO>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -725,10 +762,12 @@ template <typename T> int launch_fused(const FusedArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
-                                    const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
-                                    int H, int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1,
-                                    int skipC1, const void* skip_weight, void* stream) {
+// with optional lo planes of the output and the residual source (compensated 16-bit storage, precision mode fp16c)
+extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                                      const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                                      const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
+                                      const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
+                                      void* stream) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
@@ -754,6 +793,9 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
         (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
+  if ((out_lo || res_lo) && (esz != 2 || narrow))
+    return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype and Cout > 128", hipSuccess);
+  if (res_lo && !res_mode) return ivid_set_error("conv3x3_gn: res_lo without a residual", hipSuccess);
   if (narrow)
     return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, skip0,
                                 skipC0, skip1, skipC1, skip_weight, stream);
@@ -765,13 +807,26 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
+  a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo;
 #ifdef IVID_DEV_TIMELINE
   a.dbg = g_timeline;
 #endif
+  if (out_lo || res_lo) {
+    if (dtype == IVID_BF16) return launch_fused<__bf16, true>(a, (hipStream_t)stream);
+    return launch_fused<_Float16, true>(a, (hipStream_t)stream);
+  }
   if (dtype == IVID_BF16) return launch_fused<__bf16>(a, (hipStream_t)stream);
   if (dtype == IVID_F16) return launch_fused<_Float16>(a, (hipStream_t)stream);
   if (dtype == IVID_BF16X3) return launch_fused<bf16x3_t>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+                                    const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
+                                    int H, int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1,
+                                    int skipC1, const void* skip_weight, void* stream) {
+  return ivid_conv3x3_gn_skip_c(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, nullptr, res, nullptr, res_mode, N, H, W,
+                                Cout, stats, skip0, skipC0, skip1, skipC1, skip_weight, stream);
 }
 
 #ifdef IVID_DEV_TIMELINE

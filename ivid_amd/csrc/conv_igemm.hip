@@ -47,6 +47,11 @@ struct ConvArgs {
   int ntiles_n;
   int ntiles_total;
   float* stats;  // optional: per (32-pixel row block, cout) sum / sum of squares of the STORED output, [M/32][Cout][2]
+  // Compensated 16-bit storage (precision mode fp16c): a tensor may carry a second plane `lo` with the part of the fp32
+  // value the 16-bit rounding dropped, lo = T(v - float(T(v))), so that hi + lo keeps 22 mantissa bits.  MFMA operands
+  // read the hi plane alone (it IS the rounded operand); residual adds and GroupNorm kernels read hi + lo.
+  char* out_lo;         // optional lo plane of the NHWC output
+  const char* res_lo;   // optional lo plane of the residual source
 };
 
 // UP4: the phase-decomposed "nearest x2 upsample + conv 3x3" form (taps == 4, ivid_conv3x3_up) -- a separate
@@ -286,12 +291,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
   // (fp32 storage: a fragment's residual is 8 pieces per lane -- batching all fragments would spill, so those modes keep
   // the per-fragment prefetch)
   constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
+  constexpr bool LO = sizeof(T) == 2 && !UP4;   // compensated storage exists for the 16-bit types only
   vec_t rres[HB][NPS];
+  vec_t rres_lo[LO ? HB : 1][LO ? NPS : 1];
+  const bool res_has_lo = LO && p.res_lo != nullptr;
+  const bool out_has_lo = LO && p.out_lo != nullptr;
   auto load_res = [&](int mi) {
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       const int m = m0 + wm * WTM + mi * 32 + ps * RPP + lr, n = nbase + lc;
-      if (m < p.M && n < Cout) rres[mi % HB][ps] = *(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T));
+      if (m < p.M && n < Cout) {
+        rres[mi % HB][ps] = *(const vec_t*)(p.res + ((size_t)m * Cout + n) * sizeof(T));
+        if constexpr (LO) {
+          if (res_has_lo) rres_lo[mi % HB][ps] = *(const vec_t*)(p.res_lo + ((size_t)m * Cout + n) * sizeof(T));
+        }
+      }
     }
   };
   if (HB == MI && p.out_mode == 0 && p.res_mode == 1) {
@@ -338,6 +352,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
           if (p.res_mode == 1) {
             float rv[VE];
             vec_to_f32<T>(rres[mi % HB][ps], rv);
+            if constexpr (LO) {
+              if (res_has_lo) {
+                float rl[VE];
+                vec_to_f32<T>(rres_lo[mi % HB][ps], rl);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) rv[e] += rl[e];
+              }
+            }
 #pragma unroll
             for (int e = 0; e < VE; ++e) v[e] += rv[e];
           } else if (p.res_mode != 0) {
@@ -348,6 +370,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
               const size_t pix = ((size_t)img * Hs + (y >> 1)) * Ws + (x >> 1);
               float rv[VE];
               vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
+              if constexpr (LO) {
+                if (res_has_lo) {
+                  float rl[VE];
+                  vec_to_f32<T>(*(const vec_t*)(p.res_lo + (pix * Cout + n) * sizeof(T)), rl);
+#pragma unroll
+                  for (int e = 0; e < VE; ++e) rv[e] += rl[e];
+                }
+              }
 #pragma unroll
               for (int e = 0; e < VE; ++e) v[e] += rv[e];
             } else {  // residual source is (2H, 2W): 2x2 average pool
@@ -362,6 +392,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
                 vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) s[e] += rv[e];
+                if constexpr (LO) {
+                  if (res_has_lo) {
+                    vec_to_f32<T>(*(const vec_t*)(p.res_lo + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) s[e] += rv[e];
+                  }
+                }
               }
 #pragma unroll
               for (int e = 0; e < VE; ++e) v[e] += 0.25f * s[e];
@@ -375,9 +412,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
             mo = ((size_t)img * (2 * p.H) + 2 * y + py) * (2 * p.W) + 2 * x + px;
           }
           *(vec_t*)(p.out + (mo * Cout + n) * sizeof(T)) = ov;
+          float sv[VE];
+          vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
+          if constexpr (LO) {
+            if (out_has_lo) {   // lo plane: what the rounding dropped (exact difference, rounded once); statistics of hi + lo
+              float lv[VE];
+#pragma unroll
+              for (int e = 0; e < VE; ++e) lv[e] = v[e] - sv[e];
+              const vec_t ol = f32_to_vec<T>(lv);
+              *(vec_t*)(p.out_lo + (mo * Cout + n) * sizeof(T)) = ol;
+              vec_to_f32<T>(ol, lv);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) sv[e] += lv[e];
+            }
+          }
           if (p.stats) {
-            float sv[VE];
-            vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
               st_s[ps % NA][e] += sv[e];
@@ -488,7 +537,8 @@ static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg, int nmult = 
 
 static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
                       const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
-                      int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
+                      int W, int Cout, int taps, int tile_cfg, float* stats, void* stream, void* out_lo = nullptr,
+                      const void* res_lo = nullptr) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
@@ -501,9 +551,13 @@ static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int
   if (res_mode < 0 || res_mode > 3 || (res_mode && !res)) return ivid_set_error("conv: bad residual", hipSuccess);
   if (res_mode == 2 && ((H | W) & 1)) return ivid_set_error("conv: up-residual needs even H,W", hipSuccess);
   if ((long long)N * H * W >= (1ll << 31)) return ivid_set_error("conv: M too large", hipSuccess);
+  if ((out_lo || res_lo) && (esz != 2 || taps == 4 || out_mode != 0))
+    return ivid_set_error("conv: lo planes need a 16-bit dtype, NHWC output and taps 1 / 9", hipSuccess);
+  if (res_lo && !res_mode) return ivid_set_error("conv: res_lo without a residual", hipSuccess);
   ConvArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page();
+  a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo;
   if (!a.zero) return -1;
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0; a.nt_phase = 0;
@@ -545,6 +599,16 @@ extern "C" int ivid_conv2d(int dtype, const void* src0, int C0, const void* src1
   if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
   return conv2d_any(dtype, src0, C0, src1, C1, weight, bias, out, res, res_mode, out_mode, N, H, W, Cout, taps, tile_cfg, stats,
                     stream);
+}
+
+// ivid_conv2d with compensated 16-bit storage (precision mode fp16c): `out_lo` / `res_lo` are the optional lo planes of the
+// output and of the residual source (same NHWC shape as the hi planes; NULL = that tensor has none).
+extern "C" int ivid_conv2d_c(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
+                             const float* bias, void* out, void* out_lo, const void* res, const void* res_lo, int res_mode,
+                             int out_mode, int N, int H, int W, int Cout, int taps, int tile_cfg, float* stats, void* stream) {
+  if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  return conv2d_any(dtype, src0, C0, src1, C1, weight, bias, out, res, res_mode, out_mode, N, H, W, Cout, taps, tile_cfg, stats,
+                    stream, out_lo, res_lo);
 }
 
 // Upsample2d (nearest x2, adm.py:70-83 inside an `up` ResBlock's h_upd, adm.py:203-206) followed by the block's Conv2d 3x3,

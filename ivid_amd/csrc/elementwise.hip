@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 // Stem im2col: the model input has only 4..10 channels, so a 3x3 implicit GEMM over a channel-padded NHWC copy spends 9
 // K-steps on 94 % zeros.  Instead the 3x3 patch of every pixel is laid out as ONE K row  k = tap*Cin + c  (zero for padded
 // taps and for k >= 9 Cin), and the stem becomes a 1x1 GEMM with K = Kpad (one K-step for Cin <= 7).
-template <typename T>
+// SPLIT (16-bit types): the K row holds three segments of 9*Cin values  [x_hi | x_lo | x_hi]  (x_hi = T(x), x_lo = T(x - x_hi));
+// against weight rows  [w_hi | w_hi | w_lo]  the GEMM then accumulates x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, i.e. the stem
+// convolution to ~2^-21 instead of the 2^-11 of a single 16-bit product -- for two more K-steps of the cheapest layer.
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, int Bsrc, int Cin, int H, int W,
                                                           int Kpad, char* __restrict__ out) {
   typedef typename Elem<T>::vec vec_t;
@@ -75,12 +78,20 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     float f[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      const int k = k0 + e;
+      int k = k0 + e, seg = 0;
+      if constexpr (SPLIT) {
+        seg = k / K;
+        k -= seg * K;
+        if (seg > 2) k = K;   // padding behind the third segment
+      }
       float v = 0.f;
       if (k < K) {
         const int tap = k / Cin, c = k - tap * Cin;
         const int yy = y + tap / 3 - 1, xc = xx + tap % 3 - 1;
         if ((unsigned)yy < (unsigned)H && (unsigned)xc < (unsigned)W) v = xs[(size_t)c * HW + yy * W + xc];
+      }
+      if constexpr (SPLIT) {
+        if (seg == 1) v -= (float)(T)v;   // lo part (exact difference; rounded once by the store below)
       }
       f[e] = v;
     }
@@ -245,6 +256,20 @@ extern "C" int ivid_stem_im2col(int dtype, const float* x, int Bsrc, int N, int 
   else
     return ivid_set_error("stem_im2col: bad dtype", hipSuccess);
   return ivid_check_launch("stem_im2col");
+}
+
+extern "C" int ivid_stem_im2col_split(int dtype, const float* x, int Bsrc, int N, int Cin, int H, int W, int Kpad, void* out,
+                                      void* stream) {
+  if (ivid_esz(dtype) != 2) return ivid_set_error("stem_im2col_split: 16-bit dtypes only", hipSuccess);
+  if (Kpad % 8 || Kpad < 27 * Cin || Cin <= 0) return ivid_set_error("stem_im2col_split: bad Kpad", hipSuccess);
+  dim3 grid((H * W + 255) / 256, N);
+  if (dtype == IVID_F16)
+    hipLaunchKernelGGL((stem_im2col_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
+                       (char*)out);
+  else
+    hipLaunchKernelGGL((stem_im2col_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, x, Bsrc, Cin, H, W, Kpad,
+                       (char*)out);
+  return ivid_check_launch("stem_im2col_split");
 }
 
 extern "C" int ivid_ddim_step(const float* x_t, const float* eps_c, const float* eps_u, const ivid_ddim_coef* host_coef,

@@ -161,11 +161,13 @@ __global__ __launch_bounds__(FIN_NT) void gn_finalize_kernel(const float* __rest
 }
 
 // resample: 0 same, 1 nearest x2 up (output 2H x 2W), 2 avg-pool x2 of activated values (output H/2 x W/2)
-template <typename T, int ACT>
+// LO: the sources may carry lo planes (compensated 16-bit storage, see conv_igemm.hip ConvArgs): x = hi + lo
+template <typename T, int ACT, bool LO = false>
 __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict__ src0, int C0,
                                                          const char* __restrict__ src1, int C1,
                                                          const float* __restrict__ ab, char* __restrict__ out, int H,
-                                                         int W, int resample, int ppc) {
+                                                         int W, int resample, int ppc, const char* __restrict__ lo0 = nullptr,
+                                                         const char* __restrict__ lo1 = nullptr) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
   const int C = C0 + C1, CV = C / VE, CV0 = C0 / VE;
@@ -190,8 +192,20 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
     }
     const bool second = cv >= CV0;
     const char* base = second ? src1 : src0;
+    const char* lob = LO ? (second ? lo1 : lo0) : nullptr;
     const int Cs = second ? C1 : C0;
     const int cc = (second ? cv - CV0 : cv) * VE;
+    auto load = [&](size_t sp, float* f) {
+      vec_to_f32<T>(*(const vec_t*)(base + (sp * Cs + cc) * sizeof(T)), f);
+      if constexpr (LO) {
+        if (lob) {
+          float l[VE];
+          vec_to_f32<T>(*(const vec_t*)(lob + (sp * Cs + cc) * sizeof(T)), l);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) f[e] += l[e];
+        }
+      }
+    };
     for (int p = pbeg + p0; p < pend; p += PIF) {
       float r[VE];
       if (resample == 2) {
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
         for (int d = 0; d < 4; ++d) {
           const size_t sp = ((size_t)n * H + 2 * yo + (d >> 1)) * W + 2 * xo + (d & 1);
           float f[VE];
-          vec_to_f32<T>(*(const vec_t*)(base + (sp * Cs + cc) * sizeof(T)), f);
+          load(sp, f);
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             const float y = f[e] * a[e] + b[e];
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
           sp = (size_t)n * HWo + p;
         }
         float f[VE];
-        vec_to_f32<T>(*(const vec_t*)(base + (sp * Cs + cc) * sizeof(T)), f);
+        load(sp, f);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const float y = f[e] * a[e] + b[e];
@@ -287,7 +301,15 @@ extern "C" int ivid_gn_finalize2(const float* partial0, int C0, int nchunks0, co
 
 extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, void* out,
                              int N, int H, int W, int resample, int act, void* stream) {
+  return ivid_gn_apply_c(dtype, src0, nullptr, C0, src1, nullptr, C1, ab, out, N, H, W, resample, act, stream);
+}
+
+// with optional lo planes of the two sources (compensated 16-bit storage, precision mode fp16c); the output is a plain tensor
+extern "C" int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                               int C1, const float* ab, void* out, int N, int H, int W, int resample, int act, void* stream) {
   if (int e = check_channels(dtype, C0, C1, src1)) return e;
+  const bool lo = src0_lo || src1_lo;
+  if (lo && ivid_esz(dtype) != 2) return ivid_set_error("gn_apply: lo planes need a 16-bit dtype", hipSuccess);
   if (resample < 0 || resample > 2) return ivid_set_error("gn_apply: bad resample", hipSuccess);
   if (resample == 2 && ((H | W) & 1)) return ivid_set_error("gn_apply: avg-pool needs even H,W", hipSuccess);
   const int Ho = resample == 1 ? H * 2 : (resample == 2 ? H / 2 : H);
@@ -299,7 +321,13 @@ extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* sr
 #define LAUNCH(T, A)                                                                                              \
   hipLaunchKernelGGL((gn_apply_kernel<T, A>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
                      C1, ab, (char*)out, H, W, resample, ppc)
-  if (dtype == IVID_F32 || dtype == IVID_BF16X3) {
+#define LAUNCH_LO(T, A)                                                                                                 \
+  hipLaunchKernelGGL((gn_apply_kernel<T, A, true>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
+                     C1, ab, (char*)out, H, W, resample, ppc, (const char*)src0_lo, (const char*)src1_lo)
+  if (lo) {
+    if (dtype == IVID_F16) { if (act) LAUNCH_LO(_Float16, 1); else LAUNCH_LO(_Float16, 0); }
+    else { if (act) LAUNCH_LO(__bf16, 1); else LAUNCH_LO(__bf16, 0); }
+  } else if (dtype == IVID_F32 || dtype == IVID_BF16X3) {
     if (act) LAUNCH(float, 1); else LAUNCH(float, 0);
   } else if (dtype == IVID_F16) {
     if (act) LAUNCH(_Float16, 1); else LAUNCH(_Float16, 0);
@@ -307,5 +335,6 @@ extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* sr
     if (act) LAUNCH(__bf16, 1); else LAUNCH(__bf16, 0);
   }
 #undef LAUNCH
+#undef LAUNCH_LO
   return ivid_check_launch("gn_apply");
 }

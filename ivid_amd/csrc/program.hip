@@ -13,7 +13,7 @@
 namespace {
 
 union Slot { long long i; double f; };
-struct Op { int code; int nargs; Slot a[24]; };
+struct Op { int code; int nargs; Slot a[32]; };
 
 struct Program {
   std::vector<Op> ops;
@@ -67,6 +67,18 @@ int run_op(const Op& o, void* s) {
       return ivid_copy(P(0), CP(1), o.a[2].i, s);
     case IVID_OP_STEM_IM2COL:
       return ivid_stem_im2col(I(0), CFP(1), I(2), I(3), I(4), I(5), I(6), I(7), P(8), s);
+    case IVID_OP_CONV2D_C:
+      return ivid_conv2d_c(I(0), CP(1), I(2), CP(3), I(4), CP(5), CFP(6), P(7), P(8), CP(9), CP(10), I(11), I(12), I(13), I(14),
+                           I(15), I(16), I(17), I(18), FP(19), s);
+    case IVID_OP_CONV3X3_GN_SKIP_C:
+      return ivid_conv3x3_gn_skip_c(I(0), CP(1), I(2), CP(3), I(4), CFP(5), I(6), CP(7), CFP(8), P(9), P(10), CP(11), CP(12), I(13),
+                                    I(14), I(15), I(16), I(17), FP(18), CP(19), I(20), CP(21), I(22), CP(23), s);
+    case IVID_OP_GN_APPLY_C:
+      return ivid_gn_apply_c(I(0), CP(1), CP(2), I(3), CP(4), CP(5), I(6), CFP(7), P(8), I(9), I(10), I(11), I(12), I(13), s);
+    case IVID_OP_CONV3X3_GN_OUT_C:
+      return ivid_conv3x3_gn_out_c(I(0), CP(1), CP(2), I(3), CFP(4), CP(5), CP(6), CFP(7), FP(8), I(9), I(10), I(11), I(12), s);
+    case IVID_OP_STEM_IM2COL_SPLIT:
+      return ivid_stem_im2col_split(I(0), CFP(1), I(2), I(3), I(4), I(5), I(6), I(7), P(8), s);
     default:
       return ivid_set_error("program: unknown op code", hipSuccess);
   }
@@ -83,7 +95,7 @@ extern "C" int ivid_program_create(void** handle_out) {
 // args: nargs slots of 8 bytes each; integers and device pointers as int64, floats as double (see ivid_hip.h)
 extern "C" int ivid_program_add(void* handle, int op, const void* args, int nargs) {
   Program* p = (Program*)handle;
-  if (!p || nargs < 0 || nargs > 24 || (nargs && !args)) return ivid_set_error("program_add: bad arguments", hipSuccess);
+  if (!p || nargs < 0 || nargs > 32 || (nargs && !args)) return ivid_set_error("program_add: bad arguments", hipSuccess);
   if (p->graph) return ivid_set_error("program_add: program already captured", hipSuccess);
   Op o;
   o.code = op;

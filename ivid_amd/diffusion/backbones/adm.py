@@ -14,6 +14,9 @@ HIP launch plan (plan.py) on weights repacked once per precision:
                         at a third of the bf16 MFMA rate instead of the fp32 MFMA's sixteenth)
     precision "fp16"  : fp16 storage + fp16 MFMA, fp32 accumulate, fp32 GroupNorm/softmax/embeddings -- the
                         reference's own `use_fp16` torso (adm.py:508-514, backbones/utils.py:6-13)
+    precision "fp16c" : the fp16 kernels with COMPENSATED storage: the residual trunk is stored as two fp16 planes hi + lo
+                        (hi is the MFMA operand; residual adds, GroupNorm-apply and the head read hi + lo), stem and output
+                        head are evaluated in split form -- <= 1e-3 from the fp32 reference at the fp16 MFMA rate
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
 `use_fp16=True` configs select "fp16" like the reference; override with the extra kwarg `precision=` or the
 environment variable IVID_PRECISION.  There is no CPU path: calling forward
@@ -162,7 +165,7 @@ class AdmUnet2d(nn.Module):
                     "ivid_amd has no CPU execution path")
             _lib.load()
             dt = _lib.PRECISIONS[self.precision]
-            self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt)
+            self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt, comp=self.precision in _lib.COMPENSATED)
         return self._packed
 
     def plan(self, batch, stacked=False):

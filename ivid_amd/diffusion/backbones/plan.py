@@ -32,6 +32,12 @@ def split_pack(w2d):
     return torch.stack([hi.view(cout, k // 8, 8), lo.view(cout, k // 8, 8)], dim=2).reshape(cout, 2 * k).contiguous()
 
 
+def hi_lo(w, tdt):
+    """fp32 -> (hi, lo) in the 16-bit type tdt: hi = tdt(w), lo = tdt(w - hi) (the difference is exact in fp32)."""
+    hi = w.to(tdt)
+    return hi, (w - hi.float()).to(tdt)
+
+
 def up4_weights(w):
     """Conv2d 3x3 weights [Cout,Cin,3,3] -> the phase-summed form [4*Cout, 4*Cin] ivid_conv3x3_up takes
     (rows [phase = py*2+px][cout], columns [tap = a*2+b][cin]): behind a nearest x2 upsample (adm.py:70-83, 203-206)
@@ -56,8 +62,10 @@ class PackedWeights:
     """Weights repacked once into the kernels' layouts: conv [Cout][tap][Cin] in the compute dtype,
     Linear / GroupNorm / bias / embedding tables in fp32, all emb_layers fused into one matrix."""
 
-    def __init__(self, spec: UNetSpec, sd, device, dtype):
+    def __init__(self, spec: UNetSpec, sd, device, dtype, comp=False):
         self.dtype = dtype
+        self.comp = comp           # precision mode fp16c: compensated trunk storage, split stem and head
+        assert not comp or _lib.esz(dtype) == 2
         tdt = _TORCH_DT[dtype]
         self.kstep = 128 // _lib.esz(dtype)
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
@@ -82,9 +90,15 @@ class PackedWeights:
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
         # stem: the 3x3 patch of the few input channels is ONE K row (k = tap*Cin + c, ivid_stem_im2col), padded to a K-step
-        self.stem_k = _pad_to(9 * spec.in_channels, self.kstep)
         ws = g("input_blocks.0.0.weight").permute(0, 2, 3, 1).reshape(spec.stem_out, -1)   # [Cout, 9*Cin]
-        t["input_blocks.0.0.weight"] = mat(torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])))
+        if comp:   # split stem (ivid_stem_im2col_split): K row [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]
+            self.stem_k = _pad_to(27 * spec.in_channels, self.kstep)
+            whi, wlo = hi_lo(ws, tdt)
+            w3 = torch.cat([whi, whi, wlo], dim=1)
+            t["input_blocks.0.0.weight"] = torch.nn.functional.pad(w3, (0, self.stem_k - w3.shape[1])).contiguous()
+        else:
+            self.stem_k = _pad_to(9 * spec.in_channels, self.kstep)
+            t["input_blocks.0.0.weight"] = mat(torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])))
         t["input_blocks.0.0.bias"] = g("input_blocks.0.0.bias").contiguous()
         emb_w, emb_b = [], []
         for op in [o for st in spec.stages for o in st.ops]:
@@ -100,6 +114,9 @@ class PackedWeights:
             else:
                 vec(p + ".norm"); conv1(p + ".qkv"); conv1(p + ".proj_out")
         vec("out.0"); conv3("out.2")
+        if comp:                   # split output head (ivid_conv3x3_gn_out_c): hi and lo parts of the weights
+            wo = g("out.2.weight").permute(0, 2, 3, 1).reshape(spec.out_channels, -1)
+            t["out.2.weight"], t["out.2.weight_lo"] = [v.contiguous() for v in hi_lo(wo, tdt)]
         if dtype == _lib.BF16X3:   # the output head runs its fp32 kernel in this mode (0.05 % of the FLOPs): plain fp32 weights
             t["out.2.weight"] = g("out.2.weight").permute(0, 2, 3, 1).reshape(spec.out_channels, -1).contiguous()
         # embedding path stays fp32 in both modes (the reference never casts nn.Linear, backbones/utils.py:6-13)
@@ -146,16 +163,21 @@ class _Arena:
 
 class _Act:
     """An NHWC activation living in an arena buffer (+ optionally the GroupNorm partial statistics its producing
-    convolution wrote: fp32 [n*side*side/32][c][2])."""
-    __slots__ = ("buf", "n", "side", "c", "stats", "stats_blk")
+    convolution wrote: fp32 [n*side*side/32][c][2]).  `lo`: byte offset of the tensor's lo plane inside the same buffer
+    (compensated 16-bit storage, include/ivid_hip.h ivid_conv2d_c) or None."""
+    __slots__ = ("buf", "n", "side", "c", "stats", "stats_blk", "lo")
 
-    def __init__(self, buf, n, side, c, stats=None):
-        self.buf, self.n, self.side, self.c, self.stats = buf, n, side, c, stats
+    def __init__(self, buf, n, side, c, stats=None, lo=None):
+        self.buf, self.n, self.side, self.c, self.stats, self.lo = buf, n, side, c, stats, lo
         self.stats_blk = 32   # pixels per statistics block, set by the producing launch
 
     @property
     def ptr(self):
         return self.buf.data_ptr()
+
+    @property
+    def lo_ptr(self):
+        return self.buf.data_ptr() + self.lo if self.lo is not None else None
 
 
 class UNetPlan:
@@ -178,6 +200,7 @@ class UNetPlan:
         self._tile_up4 = int(os.environ.get("IVID_TILE_UP4", "0"))   # tuning hook: tile of the phase-form up-convolutions
         self.taps = {}
         self.dtype = weights.dtype
+        self.comp = weights.comp
         self.esz = _lib.esz(self.dtype)
         self.bsrc = bsrc
         self.n = 2 * bsrc if stacked else bsrc
@@ -226,8 +249,11 @@ class UNetPlan:
         tdt = _TORCH_DT[self.dtype]
         nbytes = act.n * act.side * act.side * act.c * self.esz
 
-        def snap(buf=act.buf, shape=(act.n, act.side, act.side, act.c)):
-            self.taps[name] = buf[:nbytes].view(tdt).view(shape).permute(0, 3, 1, 2).float().clone()
+        def snap(buf=act.buf, shape=(act.n, act.side, act.side, act.c), lo=act.lo):
+            v = buf[:nbytes].view(tdt).view(shape).permute(0, 3, 1, 2).float().clone()
+            if lo is not None:
+                v += buf[lo:lo + nbytes].view(tdt).view(shape).permute(0, 3, 1, 2).float()
+            self.taps[name] = v
         self.launches.append((None, name, snap))
 
     def _f32(self, *shape):
@@ -235,10 +261,15 @@ class UNetPlan:
         self._keep.append(t)
         return t
 
-    def _new(self, n, side, c, stats=False):
-        """stats=True: the tensor will be GroupNorm'ed later -> its producer also emits the partial statistics."""
+    def _new(self, n, side, c, stats=False, trunk=False):
+        """stats=True: the tensor will be GroupNorm'ed later -> its producer also emits the partial statistics.
+        trunk=True: a tensor of the residual stream (adm.py:222,286) -- carries a lo plane in the compensated mode."""
         st = self.arena.get(n * side * side // 32 * c * 2 * 4) if (stats and self.fuse_stats) else None
-        return _Act(self.arena.get(n * side * side * c * self.esz), n, side, c, st)
+        nb = n * side * side * c * self.esz
+        if trunk and self.comp:
+            nb = (nb + 255) // 256 * 256
+            return _Act(self.arena.get(2 * nb), n, side, c, st, lo=nb)
+        return _Act(self.arena.get(nb), n, side, c, st)
 
     def _free(self, act):
         self.arena.put(act.buf)
@@ -246,13 +277,18 @@ class UNetPlan:
             self.arena.put(act.stats)
 
     def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
-              stats=None, out_act=None):
+              stats=None, out_act=None, out_lo=None, res_lo=None):
         if out_act is not None and out_act.stats is not None:
             stats = out_act.stats
             out_act.stats_blk = self.lib.ivid_conv2d_stats_block(n, h, w, cout, self.tile_cfg)
         tile = self.tile_cfg
         if tile == 0 and taps == 1 and self._tile_1x1:
             tile = self._tile_1x1          # tuning hook (IVID_TILE_1X1): tile of the pointwise convolutions
+        if out_lo is not None or res_lo is not None:
+            self._rec("ivid_conv2d_c", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
+                      self.w[wname + ".bias"].data_ptr(), out_ptr, out_lo, res_ptr, res_lo, res_mode, out_mode, n, h, w, cout,
+                      taps, tile, stats.data_ptr() if stats is not None else None)
+            return
         self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
                   self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
                   tile, stats.data_ptr() if stats is not None else None)
@@ -293,16 +329,38 @@ class UNetPlan:
         ab = self._gn_coeffs(x0, x1, gname, film_off)
         so = {0: side, 1: side * 2, 2: side // 2}[resample]
         y = self._new(n, so, c0 + c1)
-        self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, ab.data_ptr(), y.ptr, n,
-                  side, side, resample, act)
+        lo0, lo1 = x0.lo_ptr, (x1.lo_ptr if x1 is not None else None)
+        if lo0 is not None or lo1 is not None:
+            self._rec("ivid_gn_apply_c", self.dtype, x0.ptr, lo0, c0, x1.ptr if x1 is not None else None, lo1, c1,
+                      ab.data_ptr(), y.ptr, n, side, side, resample, act)
+        else:
+            self._rec("ivid_gn_apply", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, ab.data_ptr(), y.ptr, n,
+                      side, side, resample, act)
         self.arena.put(ab)
         return y
 
-    def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode, skip=None):
+    def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode, skip=None, res_lo=None):
         """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip).  skip = (s0, s1, wname): the
-        ResBlock's 1x1 skip_connection on its raw input cat(s0, s1), accumulated in the same kernel."""
+        ResBlock's 1x1 skip_connection on its raw input cat(s0, s1), accumulated in the same kernel.  The halo transform and
+        the skip phase read the hi planes of their sources (MFMA operands); out / res may carry lo planes."""
         out.stats_blk = 128
         st = out.stats.data_ptr() if out.stats is not None else None
+        if out.lo is not None or res_lo is not None:
+            bias = self.w[wname + ".bias"]
+            s0 = s1 = sname = None
+            if skip is not None:
+                s0, s1, sname = skip
+                key = wname + "+" + sname
+                if key not in self._sum_bias:
+                    self._sum_bias[key] = (self.w[wname + ".bias"] + self.w[sname + ".bias"]).contiguous()
+                bias = self._sum_bias[key]
+            self._rec("ivid_conv3x3_gn_skip_c", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
+                      x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
+                      bias.data_ptr(), out.ptr, out.lo_ptr, res_ptr, res_lo, res_mode, out.n, out.side, out.side, out.c, st,
+                      s0.ptr if s0 is not None else None, s0.c if s0 is not None else 0,
+                      s1.ptr if s1 is not None else None, s1.c if s1 is not None else 0,
+                      self.w[sname + ".weight"].data_ptr() if sname is not None else None)
+            return
         if skip is None:
             self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
                       x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
@@ -325,7 +383,7 @@ class UNetPlan:
         so = op.res_out
         # Cout > 128: the 8x32x256 fused kernel.  Cout <= 128 (the small / SR models' first levels): its 16x32x128 variant
         # with 64-byte chunks (csrc/conv3x3_fused128.hip; not for bf16x3, which keeps gn_apply + igemm there)
-        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and so % 32 == 0
+        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and not self.comp and so % 32 == 0
         fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         h1 = self._new(n, so, op.cout, stats=True)
@@ -373,7 +431,7 @@ class UNetPlan:
             act2 = self._gn(h1, None, op.prefix + ".out_layers.0", op.emb_off, 0, 1)
             self._free(h1)
         self._first_res_done = True
-        out = self._new(n, so, op.cout, stats=True)
+        out = self._new(n, so, op.cout, stats=True, trunk=True)
         kstep = 128 // self.esz
         if op.cout <= 128:
             kstep //= 2                                       # the 128-wide variant works on 64-byte chunks
@@ -389,21 +447,21 @@ class UNetPlan:
             return out
         if op.has_skip_conv:
             assert op.mode == "same"
-            r = self._new(n, so, op.cout)
+            r = self._new(n, so, op.cout, trunk=True)   # skip_connection(x) is a term of the residual stream
             self._conv(self.dtype, x.ptr, x.c, skip.ptr if skip is not None else None, skip.c if skip is not None else 0,
-                       op.prefix + ".skip_connection", r.ptr, None, 0, 0, n, so, so, op.cout, 1)
-            res_ptr, res_mode = r.ptr, 1
+                       op.prefix + ".skip_connection", r.ptr, None, 0, 0, n, so, so, op.cout, 1, out_lo=r.lo_ptr)
+            res_ptr, res_lo, res_mode = r.ptr, r.lo_ptr, 1
         else:
             assert skip is None
             r = None
-            res_ptr, res_mode = x.ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
+            res_ptr, res_lo, res_mode = x.ptr, x.lo_ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
         if fused2:
-            self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode)
+            self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode, res_lo=res_lo)
             self.arena.put(ab2)
             self._free(h1)
         else:
             self._conv(self.dtype, act2.ptr, op.cout, None, 0, op.prefix + ".out_layers.3", out.ptr, res_ptr, res_mode, 0,
-                       n, so, so, op.cout, 9, out_act=out)
+                       n, so, so, op.cout, 9, out_act=out, out_lo=out.lo_ptr, res_lo=res_lo)
             self._free(act2)
         if r is not None:
             self._free(r)
@@ -418,9 +476,9 @@ class UNetPlan:
         a = self._new(n, side, c)
         self._rec("ivid_attention", self.dtype, qkv.ptr, a.ptr, n, side * side, op.heads)
         self._free(qkv)
-        out = self._new(n, side, c, stats=True)
+        out = self._new(n, side, c, stats=True, trunk=True)
         self._conv(self.dtype, a.ptr, c, None, 0, op.prefix + ".proj_out", out.ptr, x.ptr, 1, 0, n, side, side, c, 1,
-                   out_act=out)
+                   out_act=out, out_lo=out.lo_ptr, res_lo=x.lo_ptr)
         self._free(a)
         return out
 
@@ -444,10 +502,11 @@ class UNetPlan:
         # ---- stem ----
         S = sp.image_size
         xin = self._new(n, S, w.stem_k)
-        self._rec("ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n, sp.in_channels, S, S, w.stem_k, xin.ptr)
-        h = self._new(n, S, sp.stem_out, stats=True)
+        self._rec("ivid_stem_im2col_split" if self.comp else "ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n,
+                  sp.in_channels, S, S, w.stem_k, xin.ptr)
+        h = self._new(n, S, sp.stem_out, stats=True, trunk=True)
         self._conv(self.dtype, xin.ptr, w.stem_k, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 1,
-                   out_act=h)
+                   out_act=h, out_lo=h.lo_ptr)
         self._free(xin)
         self._tap("stem", h)
         stash = [h]
@@ -477,8 +536,13 @@ class UNetPlan:
         if (self.fuse_conv and S % 32 == 0 and sp.out_channels <= 16 and sp.final_c % (128 // self.esz) == 0
                 and os.environ.get("IVID_NO_FUSED_HEAD", "0") != "1"):
             ab = self._gn_coeffs(h, None, "out.0", None)      # one kernel: the input is read once
-            self._rec("ivid_conv3x3_gn_out", self.dtype, h.ptr, sp.final_c, ab.data_ptr(), self.w["out.2.weight"].data_ptr(),
-                      self.w["out.2.bias"].data_ptr(), self.out.data_ptr(), n, S, S, sp.out_channels)
+            if self.comp:
+                self._rec("ivid_conv3x3_gn_out_c", self.dtype, h.ptr, h.lo_ptr, sp.final_c, ab.data_ptr(),
+                          self.w["out.2.weight"].data_ptr(), self.w["out.2.weight_lo"].data_ptr(),
+                          self.w["out.2.bias"].data_ptr(), self.out.data_ptr(), n, S, S, sp.out_channels)
+            else:
+                self._rec("ivid_conv3x3_gn_out", self.dtype, h.ptr, sp.final_c, ab.data_ptr(), self.w["out.2.weight"].data_ptr(),
+                          self.w["out.2.bias"].data_ptr(), self.out.data_ptr(), n, S, S, sp.out_channels)
             self.arena.put(ab)
             self._free(h)
         else:

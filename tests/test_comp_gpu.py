@@ -1,0 +1,293 @@
+"""GPU parity of the compensated-storage entry points (precision mode fp16c; include/ivid_hip.h ivid_conv2d_c,
+ivid_conv3x3_gn_skip_c, ivid_gn_apply_c, ivid_conv3x3_gn_out_c, ivid_stem_im2col_split) through the C ABI against fp64
+torch of the same op.
+
+A tensor with a lo plane stands for the fp32 value hi + lo: the references below use the UNROUNDED residual / input where
+the kernel reads hi + lo, and 16-bit-rounded operands only where the kernel feeds an MFMA with the hi plane alone.  An
+output with a lo plane must reproduce the fp32 result of the kernel's own arithmetic to ~2^-21 (bar 4e-6) instead of the
+2^-11 of a plain fp16 store (2^-17 for a bf16 pair); the split stem / head must reproduce the UNROUNDED layer (bar 2e-5).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+DT16 = [1, 2]   # IVID_BF16, IVID_F16
+PAIR_BAR = {1: 1.5e-5, 2: 4e-6}   # hi + lo vs the fp32 result: 2 x 8 mantissa bits (bf16), 2 x 11 (fp16; fp32 summation order left)
+
+
+def planes(x, dtype):
+    """fp32 NCHW (cpu) -> (hi, lo) NHWC planes on the GPU + the fp32 value they stand for."""
+    t = G.tdt(dtype)
+    hi = x.to(t)
+    lo = (x - hi.float()).to(t)
+    val = hi.float() + lo.float()
+    return (hi.permute(0, 2, 3, 1).contiguous().cuda(), lo.permute(0, 2, 3, 1).contiguous().cuda(), val)
+
+
+def joined(hi, lo):
+    return (hi.float() + lo.float()).permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def res_for(mode, s, N, Cout, H, W):
+    if mode == 1:
+        return common.seeded_randn(s, N, Cout, H, W)
+    if mode == 2:
+        return common.seeded_randn(s, N, Cout, H // 2, W // 2)
+    if mode == 3:
+        return common.seeded_randn(s, N, Cout, 2 * H, 2 * W)
+    return None
+
+
+def add_res(y, r, mode):
+    if mode == 1:
+        return y + r.double()
+    if mode == 2:
+        return y + F.interpolate(r.double(), scale_factor=2, mode="nearest")
+    if mode == 3:
+        return y + F.avg_pool2d(r.double(), 2)
+    return y
+
+
+CONV_C = [
+    # name, N, H, W, C0, C1, Cout, k, res_mode, tile_cfg, res has a lo plane
+    ("1x1_res_same_tile1", 2, 16, 16, 128, 0, 256, 1, 1, 1, True),
+    ("3x3_res_up_tile5", 2, 16, 16, 128, 0, 192, 3, 2, 5, True),
+    ("3x3_res_down_concat", 2, 8, 8, 64, 64, 128, 3, 3, 1, True),
+    ("3x3_bigtile_res", 2, 32, 32, 128, 0, 512, 3, 1, 2, True),
+    ("3x3_tile128x384_res_plain", 2, 16, 16, 128, 0, 768, 3, 1, 6, False),   # lo output, plain residual
+    ("1x1_nores_tile4", 2, 32, 32, 128, 0, 128, 1, 0, 4, False),
+    ("3x3_mtail_cout_tail", 3, 8, 8, 64, 0, 72, 3, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("case", CONV_C, ids=[c[0] for c in CONV_C])
+def test_conv2d_c_lo_planes(case, dtype):
+    name, N, H, W, C0, C1, Cout, k, res_mode, tile, res_lo = case
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    x0 = common.seeded_randn(s, N, C0, H, W)
+    x1 = common.seeded_randn(s + 1, N, C1, H, W) if C1 else None
+    w = common.seeded_randn(s + 2, Cout, C0 + C1, k, k) / np.sqrt((C0 + C1) * k * k)
+    b = common.seeded_randn(s + 3, Cout) * 0.1
+    res = res_for(res_mode, s + 4, N, Cout, H, W)
+    x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    ref = F.conv2d(x.double(), G.rounded(w, dtype).double(), b.double(), padding=k // 2)
+    rh = rl = None
+    if res is not None:
+        if res_lo:
+            rh, rl, rval = planes(res, dtype)
+        else:
+            rh, rval = G.to_nhwc(res, dtype), G.rounded(res, dtype)
+        ref = add_res(ref, rval, res_mode)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    out_lo = torch.full_like(out, float("nan"))
+    blk = L.load().ivid_conv2d_stats_block(N, H, W, Cout, tile)
+    stats = torch.full((N * H * W // blk, Cout, 2), float("nan"), device="cuda") if (H * W) % blk == 0 else None
+    d0, d1 = G.to_nhwc(x0, dtype), (G.to_nhwc(x1, dtype) if x1 is not None else None)
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    L.call("ivid_conv2d_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(b.cuda()), L.ptr(out), L.ptr(out_lo), L.ptr(rh),
+           L.ptr(rl), res_mode, 0, N, H, W, Cout, k * k, tile, L.ptr(stats), G.stream())
+    torch.cuda.synchronize()
+    got = joined(out, out_lo)
+    e = common.rel_l2(got, ref.float())
+    e_hi = common.rel_l2(G.from_nhwc(out), ref.float())
+    G.report(f"conv_c/{name}/{G.DN[dtype]}", rel_l2=e, rel_l2_hi_plane_alone=e_hi)
+    assert torch.isfinite(got).all()
+    assert e < PAIR_BAR[dtype], f"{name}: hi + lo is {e} from the fp32 result"
+    assert e_hi > 20 * e                         # the hi plane alone carries the usual 16-bit rounding
+    assert float((out_lo.float().abs() / out.float().abs().clamp_min(1e-6)).max()) <= 2.0 ** (-8 if dtype == 1 else -11)  # |lo| <= ulp(hi)/2
+    if stats is not None:                        # GroupNorm partials describe hi + lo
+        o = (out.float() + out_lo.float()).reshape(-1, blk, Cout)
+        sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+        assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
+
+
+def test_conv2d_c_with_null_planes_equals_conv2d():
+    L = G.lib()
+    N, H, W, Cin, Cout = 2, 16, 16, 64, 128
+    x = G.to_nhwc(common.seeded_randn(1, N, Cin, H, W), 2)
+    w = G.pack_w((common.seeded_randn(2, Cout, Cin, 3, 3) / 24).permute(0, 2, 3, 1).reshape(Cout, -1), 2)
+    res = G.to_nhwc(common.seeded_randn(4, N, Cout, H, W), 2)
+    a = torch.empty((N, H, W, Cout), device="cuda", dtype=torch.float16)
+    b = torch.empty_like(a)
+    L.call("ivid_conv2d", 2, L.ptr(x), Cin, None, 0, L.ptr(w), None, L.ptr(a), L.ptr(res), 1, 0, N, H, W, Cout, 9, 0, None, G.stream())
+    L.call("ivid_conv2d_c", 2, L.ptr(x), Cin, None, 0, L.ptr(w), None, L.ptr(b), None, L.ptr(res), None, 1, 0, N, H, W, Cout, 9, 0, None,
+           G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # lo planes are refused where they cannot exist
+    lo = torch.empty_like(a)
+    assert L.load().ivid_conv2d_c(0, L.ptr(x), Cin, None, 0, L.ptr(w), None, L.ptr(b), L.ptr(lo), None, None, 0, 0, N, H, W, Cout, 9, 0,
+                                  None, G.stream()) != 0
+
+
+FUSED_C = [
+    # name, N, H, W, C0, C1, Cout, res_mode, skip channels (S0, S1)
+    ("same_res_c256", 2, 32, 32, 64, 0, 256, 1, (0, 0)),
+    ("up_res_c192", 2, 32, 32, 64, 0, 192, 2, (0, 0)),
+    ("down_res_avgpool_c160", 2, 16, 32, 64, 0, 160, 3, (0, 0)),
+    ("concat_nores_c320", 1, 8, 64, 64, 64, 320, 0, (0, 0)),
+    ("skip_cat_128+64_c192", 2, 16, 32, 64, 0, 192, 0, (128, 64)),
+]
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("case", FUSED_C, ids=[c[0] for c in FUSED_C])
+def test_conv3x3_gn_skip_c_lo_planes(case, dtype):
+    name, N, H, W, C0, C1, Cout, res_mode, (S0, S1) = case
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    Cc = C0 + C1
+    x0 = common.seeded_randn(s, N, C0, H, W)
+    x1 = common.seeded_randn(s + 1, N, C1, H, W) if C1 else None
+    a = 0.5 + 0.5 * torch.rand(N, Cc, generator=torch.Generator().manual_seed(s))
+    b = 0.3 * common.seeded_randn(s + 2, N, Cc)
+    w = common.seeded_randn(s + 3, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    bias = common.seeded_randn(s + 4, Cout) * 0.1
+    res = res_for(res_mode, s + 5, N, Cout, H, W)
+    x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    act = G.rounded(F.silu(x * a[:, :, None, None] + b[:, :, None, None]), dtype)
+    ref = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1)
+    sk0 = sk1 = wsk = None
+    if S0:
+        k0 = common.seeded_randn(s + 6, N, S0, H, W)
+        k1 = common.seeded_randn(s + 7, N, S1, H, W) if S1 else None
+        wk = common.seeded_randn(s + 8, Cout, S0 + S1, 1, 1) / np.sqrt(S0 + S1)
+        ref = ref + F.conv2d(G.rounded(k0 if k1 is None else torch.cat([k0, k1], 1), dtype).double(), G.rounded(wk, dtype).double())
+        sk0, sk1 = G.to_nhwc(k0, dtype), (G.to_nhwc(k1, dtype) if k1 is not None else None)
+        wsk = G.pack_w(wk.reshape(Cout, -1), dtype)
+    rh = rl = None
+    if res is not None:
+        rh, rl, rval = planes(res, dtype)
+        ref = add_res(ref, rval, res_mode)
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    out_lo = torch.full_like(out, float("nan"))
+    stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
+    d0, d1 = G.to_nhwc(x0, dtype), (G.to_nhwc(x1, dtype) if x1 is not None else None)
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    L.call("ivid_conv3x3_gn_skip_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), 0, L.ptr(wp), L.ptr(bias.cuda()), L.ptr(out),
+           L.ptr(out_lo), L.ptr(rh), L.ptr(rl), res_mode, N, H, W, Cout, L.ptr(stats), L.ptr(sk0), S0, L.ptr(sk1), S1, L.ptr(wsk),
+           G.stream())
+    torch.cuda.synchronize()
+    got = joined(out, out_lo)
+    e = common.rel_l2(got, ref.float())
+    e_hi = common.rel_l2(G.from_nhwc(out), ref.float())
+    G.report(f"conv3x3_gn_c/{name}/{G.DN[dtype]}", rel_l2=e, rel_l2_hi_plane_alone=e_hi)
+    assert torch.isfinite(got).all()
+    # the halo transform's hardware exp / rcp move a few activations across a 16-bit rounding boundary (~1e-5 on the output)
+    assert e < (2e-4 if dtype == 1 else 6e-5), f"{name}: hi + lo is {e} from the fp32 result"
+    assert e_hi > 4 * e
+    o = (out.float() + out_lo.float()).reshape(N, H // 4, 4, W // 32, 32, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 128, Cout)
+    sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("resample,act", [(0, 1), (0, 0), (1, 1), (2, 1)])
+def test_gn_apply_c_reads_hi_plus_lo(dtype, resample, act):
+    L = G.lib()
+    N, H, W, C0, C1 = 2, 16, 16, 64, 128
+    x0, x1 = common.seeded_randn(1, N, C0, H, W) * 3, common.seeded_randn(2, N, C1, H, W)
+    a = 0.5 + 0.5 * torch.rand(N, C0 + C1, generator=torch.Generator().manual_seed(3))
+    b = 0.3 * common.seeded_randn(4, N, C0 + C1)
+    h0, l0, v0 = planes(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype)                                   # second source without a lo plane
+    y = torch.cat([v0, G.rounded(x1, dtype)], 1).double() * a[:, :, None, None].double() + b[:, :, None, None].double()
+    if act:
+        y = F.silu(y)
+    if resample == 1:
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    elif resample == 2:
+        y = F.avg_pool2d(y, 2)
+    Ho, Wo = y.shape[2:]
+    out = torch.full((N, Ho, Wo, C0 + C1), float("nan"), device="cuda", dtype=G.tdt(dtype))
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    L.call("ivid_gn_apply_c", dtype, L.ptr(h0), L.ptr(l0), C0, L.ptr(d1), None, C1, L.ptr(ab), L.ptr(out), N, H, W, resample, act,
+           G.stream())
+    torch.cuda.synchronize()
+    got = G.from_nhwc(out)
+    # exact up to the output rounding: compare against the fp64 result rounded the same way
+    want = G.rounded(y.float(), dtype)
+    ulp = 2.0 ** (-7 if dtype == 1 else -10)
+    assert float(((got - want).abs() / want.abs().clamp_min(1e-3)).max()) <= 1.01 * ulp
+    assert common.rel_l2(got[:, :C0], y.float()[:, :C0]) < (3e-3 if dtype == 1 else 4e-4)
+    # ... and the lo plane matters: the hi plane alone is measurably farther from the fp64 result before rounding
+    out2 = torch.empty_like(out)
+    L.call("ivid_gn_apply", dtype, L.ptr(h0), C0, L.ptr(d1), C1, L.ptr(ab), L.ptr(out2), N, H, W, resample, act, G.stream())
+    torch.cuda.synchronize()
+    assert not torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 128, 4, True), (1, 16, 64, 256, 4, False), (2, 8, 32, 64, 7, True)])
+def test_conv3x3_gn_out_c_split_head(dtype, shape):
+    """Split output head: GN-apply + SiLU + conv3x3 evaluated to ~2^-21 on hi + lo input, against the UNROUNDED fp64 layer."""
+    N, H, W, Cc, Cout, with_lo = shape
+    L = G.lib()
+    x = common.seeded_randn(11, N, Cc, H, W) * 2
+    a = 0.5 + 0.5 * torch.rand(N, Cc, generator=torch.Generator().manual_seed(5))
+    b = 0.3 * common.seeded_randn(12, N, Cc)
+    w = common.seeded_randn(13, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    bias = common.seeded_randn(14, Cout) * 0.1
+    if with_lo:
+        xh, xl, xv = planes(x, dtype)
+    else:
+        xh, xl, xv = G.to_nhwc(x, dtype), None, G.rounded(x, dtype)
+    ref = F.conv2d(F.silu(xv.double() * a[:, :, None, None].double() + b[:, :, None, None].double()), w.double(), bias.double(),
+                   padding=1).float()
+    t = G.tdt(dtype)
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    whi = w2.to(t)
+    wlo = (w2 - whi.float()).to(t)
+    out = torch.full((N, Cout, H, W), float("nan"), device="cuda")
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    L.call("ivid_conv3x3_gn_out_c", dtype, L.ptr(xh), L.ptr(xl), Cc, L.ptr(ab), L.ptr(whi.cuda()), L.ptr(wlo.cuda()), L.ptr(bias.cuda()),
+           L.ptr(out), N, H, W, Cout, G.stream())
+    torch.cuda.synchronize()
+    e = common.rel_l2(out.cpu(), ref)
+    out1 = torch.empty_like(out)
+    L.call("ivid_conv3x3_gn_out", dtype, L.ptr(xh), Cc, L.ptr(ab), L.ptr(whi.cuda()), L.ptr(bias.cuda()), L.ptr(out1), N, H, W, Cout,
+           G.stream())
+    torch.cuda.synchronize()
+    e1 = common.rel_l2(out1.cpu(), ref)
+    G.report(f"conv3x3_gn_out_c/{G.DN[dtype]}/{N}x{H}x{W}x{Cc}", rel_l2_split=e, rel_l2_single_product=e1)
+    assert torch.isfinite(out).all()
+    assert e < (2e-4 if dtype == 1 else 2e-5), e          # bf16 hi + lo = 16 bits, fp16 hi + lo = 22 bits
+    assert e1 > 10 * e
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("cin", [4, 10])
+def test_stem_split_reproduces_the_unrounded_convolution(dtype, cin):
+    """ivid_stem_im2col_split + ivid_conv2d(taps = 1) with [w_hi | w_hi | w_lo] rows vs F.conv2d in fp64 on UNROUNDED operands."""
+    L = G.lib()
+    N, Bsrc, H, W, Cout = 4, 2, 32, 32, 128
+    x = common.seeded_randn(21, Bsrc, cin, H, W)
+    w = common.seeded_randn(22, Cout, cin, 3, 3) / np.sqrt(cin * 9)
+    bias = common.seeded_randn(23, Cout) * 0.1
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1).float().repeat(N // Bsrc, 1, 1, 1)
+    t = G.tdt(dtype)
+    K9 = 9 * cin
+    Kpad = (3 * K9 + 63) // 64 * 64
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, K9)
+    whi = w2.to(t)
+    wlo = (w2 - whi.float()).to(t)
+    w3 = F.pad(torch.cat([whi, whi, wlo], 1), (0, Kpad - 3 * K9)).contiguous().cuda()
+    col = torch.full((N, H, W, Kpad), float("nan"), device="cuda", dtype=t)
+    L.call("ivid_stem_im2col_split", dtype, L.ptr(x.cuda()), Bsrc, N, cin, H, W, Kpad, L.ptr(col), G.stream())
+    out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=t)
+    out_lo = torch.full_like(out, float("nan"))
+    L.call("ivid_conv2d_c", dtype, L.ptr(col), Kpad, None, 0, L.ptr(w3), L.ptr(bias.cuda()), L.ptr(out), L.ptr(out_lo), None, None, 0, 0,
+           N, H, W, Cout, 1, 0, None, G.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(col.float()).all()
+    e = common.rel_l2(joined(out, out_lo), ref)
+    G.report(f"stem_split/{G.DN[dtype]}/cin{cin}", rel_l2=e)
+    assert e < (1e-4 if dtype == 1 else 5e-6), e

@@ -2,10 +2,10 @@
 AdmUnet2d forward, stacked CFG forward, DDIM / DDPM / inpaint chains — against the committed golden
 fixtures (outputs of the live reference) and the oracle on the same seeded inputs.
 
-Bars (rel-L2 of one forward vs the reference's fp32 output): fp32 and bf16x3 modes <= 1e-3 as
-BASELINE.json's north_star states (measured ~1e-6 / ~1e-5); fp16 <= 3e-3 (the reference's own fp16 torso
-is 1.6e-3 from its fp32 path); bf16 <= 1.5e-2 (8 mantissa bits; ~2x the measured value so that
-a regression shows).  Every measured value is written to gpurun_out/parity_report.json.
+Bars (rel-L2 of one forward vs the reference's fp32 output): fp32, bf16x3 and fp16c (fp16 MFMA with compensated
+storage, the bench headline) <= 1e-3 as BASELINE.json's north_star states (measured ~1e-6 / ~1e-5 / ~8.7e-4);
+plain fp16 <= 1.5e-3 (measured 1.07-1.25e-3; the reference's own fp16 torso is 1.3-1.5e-3 from its fp32 path);
+bf16 <= 1.2e-2 (measured 8.0e-3 - 1.0e-2).  Every measured value is written to gpurun_out/parity_report.json.
 """
 import pytest
 import torch
@@ -17,7 +17,7 @@ from oracle import adm_oracle, sampler_oracle
 pytestmark = pytest.mark.gpu
 PARITY_BAR = 1e-3
 # precision -> bar on one forward's rel-L2 vs the reference fp32 output
-MODE_BAR = {"bf16": 1.5e-2, "fp16": 3e-3, "bf16x3": PARITY_BAR}
+MODE_BAR = {"bf16": 1.2e-2, "fp16": 1.5e-3, "fp16c": PARITY_BAR, "bf16x3": PARITY_BAR}
 
 
 def build(args, seed, precision):
@@ -112,7 +112,7 @@ def test_stacked_cfg_forward_shares_the_class_independent_prefix_bit_exactly(pre
         assert ncopy[0] == 2 and ncopy[1] == 0, ncopy
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "bf16x3"])
 @pytest.mark.parametrize("name,args,seed", [("mini_fwd", C.MINI, 0), ("mini_cond_fwd", C.MINI_COND, 2)])
 def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
     m, sd = build(args, seed, precision)
@@ -237,13 +237,13 @@ def test_config1_small128_ddim10_matches_reference_golden():
     G.report("chain/config1_bs2_fp32", samples=e, x0_first=C.rel_l2(res.pred_x_0[0].cpu(), g["x0_first"]))
     assert e < PARITY_BAR
     # the same chain in the MFMA-speed parity mode (split-bf16) and, reported, in the 16-bit modes
-    for prec in ("bf16x3", "fp16", "bf16"):
+    for prec in ("bf16x3", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
         torch.manual_seed(1)
         r2 = smp.sample(2, noise=x_T.cuda(), steps=10, verbose=False, noise_fn=_cpu_noise_fn())
         ep = C.rel_l2(r2.samples.cpu(), g["samples"])
         G.report("chain/config1_bs2_" + prec, samples=ep)
-        if prec == "bf16x3":
+        if prec in ("bf16x3", "fp16c"):
             assert ep < PARITY_BAR, ep
         else:
             assert ep < 10 * MODE_BAR[prec], (prec, ep)   # drift check of a 10-step chain
@@ -260,6 +260,52 @@ def test_config1_small128_ddim10_matches_reference_golden():
     assert e4 < PARITY_BAR
 
 
+def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
+    """BASELINE config 2 ITSELF as a chain (tests/golden/make_golden_c2.py: the live reference's large cfg model,
+    ClassifierFreeGuidance strength 0.5 + DdimSampler 50 steps, eta 0, bs 2): the samples of every precision mode against the
+    reference's, and the bar of BASELINE.json's north_star (1e-3) on the modes that claim it -- fp32, bf16x3 and fp16c, the
+    mode bench.py reports as its headline."""
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("large128_ddim50_cfg")
+    m, _ = build(C.LARGE128, 4, "fp32")
+    fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    smp = samplers.DdimSampler(fw)
+    x_T = C.seeded_randn(2024, 2, 4, 128, 128)
+    assert abs(float(x_T.double().sum()) - float(g["x_checksum"])) < 1e-6
+    cls = torch.from_numpy(g["classes"]).cuda()
+    errs = {}
+    for prec in ("fp32", "bf16x3", "fp16c", "fp16", "bf16"):
+        m.set_precision(prec)
+        torch.manual_seed(3)
+        res = smp.sample(2, noise=x_T.cuda(), classes=cls, steps=int(g["steps"]), strength=float(g["strength"]), verbose=False,
+                         noise_fn=_cpu_noise_fn())
+        errs[prec] = dict(samples=C.rel_l2(res.samples.cpu(), g["samples"]), x0_first=C.rel_l2(res.pred_x_0[0].cpu(), g["x0_first"]),
+                          x0_mid=C.rel_l2(res.pred_x_0[len(res.pred_x_0) // 2].cpu(), g["x0_mid"]),
+                          x0_last=C.rel_l2(res.pred_x_0[-1].cpu(), g["x0_last"]))
+        G.report("chain/config2_bs2_" + prec, **errs[prec])
+        assert torch.isfinite(res.samples).all()
+    print("config 2 chain, samples rel-L2 vs the reference:", {k: v["samples"] for k, v in errs.items()})
+    assert errs["fp32"]["samples"] < 1e-4
+    for prec in ("bf16x3", "fp16c"):
+        assert errs[prec]["samples"] < PARITY_BAR, (prec, errs[prec])
+    assert errs["fp16"]["samples"] < 10 * MODE_BAR["fp16"] and errs["bf16"]["samples"] < 10 * MODE_BAR["bf16"]
+
+
+def test_fp16c_keeps_the_trunk_as_hi_plus_lo_planes():
+    """Precision mode fp16c: the launch plan routes every tensor of the residual stream through the `_c` entry points (lo
+    planes written and read), the stem through ivid_stem_im2col_split and the head through the split form; plain fp16 uses none."""
+    m, _ = build(C.MINI, 0, "fp16c")
+    g, x, t, cls = fwd_inputs("mini_fwd", C.MINI, 0, 2)
+    m(x.cuda(), t.cuda(), cls.cuda())
+    names = [name for _, name, _ in m.plan(2, False).launches]
+    assert "ivid_stem_im2col_split" in names and "ivid_conv3x3_gn_out_c" in names
+    assert names.count("ivid_conv3x3_gn_skip_c") + names.count("ivid_conv2d_c") >= len(m.spec.res_ops())
+    assert "ivid_gn_apply_c" in names                       # attention norm / sub-32^2 blocks read hi + lo
+    m2, _ = build(C.MINI, 0, "fp16")
+    m2(x.cuda(), t.cuda(), cls.cuda())
+    assert not [n for _, n, _ in m2.plan(2, False).launches if n.endswith("_c") or n.endswith("_split")]
+
+
 def test_sr256_forward_and_superres_chain_match_oracle():
     """BASELINE config 5's model (SR 128->256: 8 input channels, attention at T = 4096 / 1024 / 256): one fp32 forward
     against the oracle on the host, and SuperResCFG + DDIM through `super_resolve` on the 64-px mini variant."""
@@ -274,7 +320,7 @@ def test_sr256_forward_and_superres_chain_match_oracle():
     e = C.rel_l2(out, ref)
     G.report("unet/sr256_fwd/fp32", rel_l2=e)
     assert e < 1e-4
-    for prec in ("bf16x3", "fp16", "bf16"):          # SR-256 deviation of the reduced-precision modes (attention share 13.6 %)
+    for prec in ("bf16x3", "fp16c", "fp16", "bf16"):  # SR-256 deviation of the reduced-precision modes (attention share 13.6 %)
         m.set_precision(prec)
         ep = C.rel_l2(m(x.cuda(), t.cuda(), cls.cuda()).cpu(), ref)
         G.report("unet/sr256_fwd/" + prec, rel_l2=ep)
