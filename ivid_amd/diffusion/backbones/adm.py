@@ -176,8 +176,15 @@ class AdmUnet2d(nn.Module):
         p = self._plans.pop(key, None)
         if p is None:
             while len(self._plans) >= self.max_plans:
-                old = self._plans.pop(next(iter(self._plans)))      # dict order = recency (re-inserted on every hit)
+                okey = next(iter(self._plans))
+                old = self._plans.pop(okey)                         # dict order = recency (re-inserted on every hit)
                 torch.cuda.synchronize(self.device)                 # its buffers may still be in flight
+                self._evictions = getattr(self, "_evictions", 0) + 1
+                if self._evictions in (1, 10, 100):                 # a caller cycling through > max_plans shapes thrashes: say so
+                    import warnings
+                    warnings.warn(f"AdmUnet2d: launch plan for (batch, stacked) = {okey} evicted ({old.arena.total_bytes() >> 20} MiB "
+                                  f"arena; {self._evictions} evictions so far) to make room for {key}; every miss rebuilds arena + "
+                                  f"hipGraph.  Raise IVID_MAX_PLANS (now {self.max_plans}) if the workload cycles through more shapes.")
                 del old
             p = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
         self._plans[key] = p

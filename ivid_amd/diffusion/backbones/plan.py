@@ -574,9 +574,15 @@ class UNetPlan:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         if self.program is not None:
-            assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == self.x_in.shape, "x must be fp32 NCHW"
-            t64 = times.to(torch.int64).contiguous()
-            c64 = classes.to(torch.int64).contiguous() if (classes is not None and self.spec.num_classes is not None) else None
+            # the C call copies device -> device from raw pointers: everything must live on the plan's device
+            if x.device != self.x_in.device or x.dtype != torch.float32 or x.shape != self.x_in.shape or not x.is_contiguous():
+                raise ValueError(f"x must be a contiguous fp32 {tuple(self.x_in.shape)} tensor on {self.x_in.device}, got "
+                                 f"{x.dtype} {tuple(x.shape)} on {x.device}")
+            if times.shape != (self.bsrc,) or (classes is not None and classes.shape != (self.bsrc,)):
+                raise ValueError(f"times / classes must have shape ({self.bsrc},)")
+            t64 = times.to(device=self.x_in.device, dtype=torch.int64).contiguous()
+            c64 = (classes.to(device=self.x_in.device, dtype=torch.int64).contiguous()
+                   if (classes is not None and self.spec.num_classes is not None) else None)
             with torch.cuda.stream(self.stream):
                 _lib.call("ivid_unet_forward", self.program, x.data_ptr(), t64.data_ptr(), c64.data_ptr() if c64 is not None else None,
                           None, 1 if use_graph else 0, C.c_void_p(self.stream.cuda_stream))

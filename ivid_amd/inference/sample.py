@@ -189,6 +189,9 @@ def main(argv=None):
     else:
         seeds = parse_int_list(cfg.seeds)
         num_samples = len(seeds)
+    # the reference draws random classes / cameras ONCE in the parent and passes the lists to every rank (sample.py:296-336):
+    # here every rank draws them itself from one common seed, then takes its shard of the same lists
+    np.random.seed(parallel.common_draw_seed() % (1 << 32))
     classes = None
     num_classes = cfg_uncond["backbone"]["args"].get("num_classes")
     if num_classes is not None:

@@ -50,15 +50,40 @@ def save_png(path, chw):
     Image.fromarray(to_uint8_image(chw)).save(path)
 
 
-def save_grid(path, nchw, nrow):
+def make_grid(tensor, nrow=8, padding=2, normalize=False, value_range=None, pad_value=0.0):
+    """torchvision.utils.make_grid as the reference calls it through utils.save_image (inference/sample.py:158-165: `nrow`,
+    `normalize=True, value_range=(-1, 1)`, default padding 2 / pad_value 0): [N,C,H,W] -> [3, ymaps*(H+2)+2, xmaps*(W+2)+2].
+    Single-channel images are repeated to 3 channels; normalize clamps to value_range and maps it to [0, 1]; image k sits at
+    row k // xmaps, column k % xmaps behind a `padding`-pixel border of pad_value; ONE image is returned without a border."""
+    t = torch.as_tensor(tensor).detach().float().cpu()
+    if t.dim() == 3:
+        t = t[None]
+    if t.shape[1] == 1:
+        t = t.repeat(1, 3, 1, 1)
+    if normalize:
+        lo, hi = (float(value_range[0]), float(value_range[1])) if value_range is not None else (float(t.min()), float(t.max()))
+        t = (t.clamp(lo, hi) - lo) / max(hi - lo, 1e-5)
+    if t.shape[0] == 1:
+        return t[0]
+    n = t.shape[0]
+    xmaps = min(nrow, n)
+    ymaps = (n + xmaps - 1) // xmaps
+    h, w = t.shape[2] + padding, t.shape[3] + padding
+    grid = t.new_full((t.shape[1], h * ymaps + padding, w * xmaps + padding), pad_value)
+    for k in range(n):
+        y, x = divmod(k, xmaps)
+        grid[:, y * h + padding:(y + 1) * h, x * w + padding:(x + 1) * w] = t[k]
+    return grid
+
+
+def save_grid(path, nchw, nrow, padding=2, normalize=True, value_range=(-1, 1)):
+    """torchvision.utils.save_image(nchw, path, nrow=nrow, normalize=True, value_range=(-1, 1)) (inference/sample.py:158-165):
+    make_grid, then `mul(255).add(0.5).clamp(0, 255)` truncated to uint8 (round to nearest), PNG."""
     from PIL import Image
-    n, c, h, w = nchw.shape
-    rows = (n + nrow - 1) // nrow
-    canvas = np.zeros((rows * h, nrow * w, 3), dtype=np.uint8)
-    for i in range(n):
-        canvas[(i // nrow) * h:(i // nrow + 1) * h, (i % nrow) * w:(i % nrow + 1) * w] = to_uint8_image(nchw[i, :3])
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    Image.fromarray(canvas).save(path)
+    grid = make_grid(nchw, nrow=nrow, padding=padding, normalize=normalize, value_range=value_range)
+    arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    Image.fromarray(arr).save(path)
 
 
 _INFERNO = None

@@ -39,7 +39,6 @@ def spawn_one_process_per_gpu(script, argv, nproc=None, module=False):
     process was NOT started by a launcher (no WORLD_SIZE) and the node has more than one GPU, re-exec `script argv`
     under torch.distributed.run with one rank per GPU and return its exit code; otherwise return None and the caller
     carries on as the single rank (or as the rank torchrun made it)."""
-    import socket
     import subprocess
     import sys
     if "WORLD_SIZE" in os.environ:
@@ -48,16 +47,33 @@ def spawn_one_process_per_gpu(script, argv, nproc=None, module=False):
         nproc = torch.cuda.device_count() if torch.cuda.is_available() else 1
     if nproc <= 1:
         return None
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port)] + (["-m"] if module else []) + [script] + list(argv)
+    # torchrun's own c10d rendezvous picks the port (--standalone): no bind-then-close race with another process
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={nproc}"] + (["-m"] if module else []) + [script] + list(argv)
     env = dict(os.environ)
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in env or "OMP_NUM_THREADS" not in env:
+        print("[ivid_amd] starting %d ranks with HSA_ENABLE_IPC_MODE_LEGACY=%s OMP_NUM_THREADS=%s (set them to override)"
+              % (nproc, env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), env.get("OMP_NUM_THREADS", "8")), file=sys.stderr)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    # random draws the reference makes ONCE in the parent and hands to every rank (classes / viewset 'random',
+    # sample.py:296-336): the ranks re-draw them from this common seed, so each rank's shard is a shard of ONE list
+    env.setdefault("IVID_DRAW_SEED", str(int.from_bytes(os.urandom(4), "little")))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print("[ivid_amd] the %d-rank launch failed (exit %d).  If torch.distributed / RCCL cannot initialise on this node, run a "
+              "single rank instead: WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 python -m %s ... (or CUDA_VISIBLE_DEVICES=<one gpu>)"
+              % (nproc, rc, script), file=sys.stderr)
+    return rc
+
+
+def common_draw_seed():
+    """One seed for the random draws that must agree on all ranks: IVID_DRAW_SEED when the launcher set it, else rank 0's
+    fresh seed (exchanged with one all_gather when there is more than one rank)."""
+    seed = int(os.environ["IVID_DRAW_SEED"]) if os.environ.get("IVID_DRAW_SEED") else int.from_bytes(os.urandom(4), "little")
+    if rank_world()[1] > 1:
+        seed = int(gather_scalars(seed)[0])
+    return seed
 
 
 def shard(seq, rank=None, world=None):

@@ -43,11 +43,20 @@ def project_depth(depth, near=0.5, far=100, mode="z_buffer"):
 
 
 def _builder(S, device="cuda"):
-    """One cached batch-of-one WarpRenderer per image size: the mesh-building scratch of depth_to_mesh."""
-    key = (S, str(device))
+    """One cached batch-of-one WarpRenderer per (image size, RESOLVED device): the mesh-building scratch of depth_to_mesh.
+    'cuda' means the current device at the time of the call, so a process / thread that switched GPUs gets its own."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (S, str(dev))
     if key not in _mesh_builders:
-        _mesh_builders[key] = WarpRenderer(1, S, 1, 1, device=device)
+        _mesh_builders[key] = WarpRenderer(1, S, 1, 1, device=dev)
     return _mesh_builders[key]
+
+
+def clear_mesh_builders():
+    """Release the cached mesh-building renderers (their device buffers)."""
+    _mesh_builders.clear()
 
 
 def depth_to_mesh(depth, padding=None, fov=45, modelview=None, atol=None, rtol=None, erode_rgb=None, cal_normal=False):

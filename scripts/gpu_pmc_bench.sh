@@ -1,14 +1,18 @@
 #!/bin/bash
 # HBM traffic of the conv kernel family in the BENCH workload: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters
-# only + --kernel-trace) over `python bench.py`, summarised to gpurun_out/pmc_bench/traffic.json (copy to profiles/).
+# only + --kernel-trace, one counter per pass as MI355X_MICROARCH.md prescribes) over `python bench.py --precision $PREC`,
+# summarised to gpurun_out/pmc_bench_$PREC/traffic.json (copy to profiles/r03_pmc_traffic_$PREC.json).
+#   IVID_COMMIT=$(git rev-parse --short HEAD) PREC=fp16c bash scripts/gpu_pmc_bench.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/pmc_bench
+PREC=${PREC:-fp16c}
+D=gpurun_out/pmc_bench_$PREC
+mkdir -p $D
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf gpurun_out/pmc_bench/$c
-  IVID_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_bench/$c -o p -- \
-    python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-breakdown --no-parity-mode > gpurun_out/pmc_bench/$c.log 2>&1
+  rm -rf $D/$c
+  IVID_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/$c -o p -- \
+    python bench.py --precision $PREC --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-breakdown --no-parity-mode > $D/$c.log 2>&1
   echo "$c exit $?"
 done
-python scripts/pmc_traffic.py gpurun_out/pmc_bench > gpurun_out/pmc_bench/traffic.json && cat gpurun_out/pmc_bench/traffic.json
-find gpurun_out/pmc_bench -name "*.csv" -size +5M -delete
+python scripts/pmc_traffic.py $D $PREC > $D/traffic.json && cat $D/traffic.json
+find $D -name "*.csv" -size +5M -delete

@@ -7,8 +7,26 @@ import glob
 import json
 import sys
 
+import hashlib
+import os
+
 root = sys.argv[1]
-out = {"unit": "bytes per conv-family launch (mean over all conv launches of the bench forward)", "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha():   # as bench.py: ties the profile to the kernel sources it was taken from
+    h = hashlib.sha256()
+    d = os.path.join(repo, "ivid_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+out = {"precision": sys.argv[2] if len(sys.argv) > 2 else None, "commit": os.environ.get("IVID_COMMIT"), "csrc_sha": csrc_sha(),
+       "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --precision <mode> --steps 1 --warmup 1 (IVID_NO_GRAPH=1)",
+       "unit": "bytes per conv-family launch (mean over all conv launches of the bench forward)", "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{root}/{c}/**/*counter_collection.csv", recursive=True)

@@ -160,7 +160,7 @@ def test_cli_main_writes_the_reference_output_tree(tmp_path):
         assert len(scene) == 27 and scene[0]["color"].shape == (32, 32, 3) and scene[26]["modelview"].shape == (4, 4)
     from PIL import Image
     g = Image.open(os.path.join(root, "grids", "rgb_class003_seed00003.png"))
-    assert g.size == (9 * 32, 3 * 32)                       # 3 rows x 9 columns (reorder + nrow 9, sample.py:161-165)
+    assert g.size == (9 * 34 + 2, 3 * 34 + 2)               # torchvision grid: 3 rows x 9 columns, 2-px borders (sample.py:161-165)
     # the models came up in the reference's precision for use_fp16 configs
     assert S_.parse_int_list("3,5-6") == [3, 5, 6]
 

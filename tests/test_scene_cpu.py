@@ -171,3 +171,58 @@ def test_render_trajectories_follow_render_py():
         assert np.allclose(tr[k], camera.orbit(0.6 * np.cos(ts[k]), 0.15 * np.sin(ts[k])))
     rnd = R.trajectory("random", 60, 5, rng=np.random.default_rng(0))
     assert len(rnd) == 5 and all(len(r) == 1 and np.asarray(r[0]).shape == (4, 4) for r in rnd)
+
+
+def _tv_make_grid(tensor, nrow, padding=2, value_range=(-1, 1), pad_value=0.0):
+    """torchvision.utils.make_grid(normalize=True), restated from its documented algorithm with torch ops in ITS order
+    (clamp_, sub_, div_, narrow().copy_) -- independent of the product's slicing code."""
+    import math
+    t = tensor.clone().float()
+    if t.size(1) == 1:
+        t = torch.cat((t, t, t), 1)
+    lo, hi = value_range
+    t.clamp_(min=lo, max=hi)
+    t.sub_(lo).div_(max(hi - lo, 1e-5))
+    if t.size(0) == 1:
+        return t.squeeze(0)
+    nmaps = t.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(math.ceil(float(nmaps) / xmaps))
+    height, width = int(t.size(2) + padding), int(t.size(3) + padding)
+    grid = t.new_full((t.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, y * height + padding, height - padding).narrow(2, x * width + padding, width - padding).copy_(t[k])
+            k = k + 1
+    return grid
+
+
+def test_save_grid_is_torchvision_save_image(tmp_path):
+    """inference/sample.py:158-165: utils.save_image(x, path, nrow, normalize=True, value_range=(-1, 1)) -- 2-px borders of 0,
+    clamp to [-1, 1] -> [0, 1], `mul(255).add(0.5).clamp(0, 255)` to uint8.  The reference's 3x9 grid of 128^2 views is 1172 x 392."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 3, 4, 6, generator=g) * 0.8          # 5 images on a 2 x 3 grid: one empty cell, values beyond [-1, 1]
+    p = str(tmp_path / "g" / "grid.png")
+    U.save_grid(p, x, 3)
+    img = np.asarray(Image.open(p))
+    assert img.shape == (2 * 6 + 2, 3 * 8 + 2, 3)
+    want = _tv_make_grid(x, 3).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    assert np.array_equal(img, want)
+    # hand-computed cells: border and the empty sixth cell are 0; image 4 sits at row 1, column 1
+    assert img[:2].max() == 0 and img[:, :2].max() == 0 and img[8:, 18:].max() == 0
+    v = float(x[4, 1, 2, 3])
+    assert img[8 + 2, 10 + 3, 1] == int(min(max((min(max(v, -1.0), 1.0) + 1) / 2 * 255 + 0.5, 0), 255))
+    # rounding, not truncation: 0.0 -> 127.5 + 0.5 = 128
+    U.save_grid(p, torch.zeros(2, 3, 2, 2), 2)
+    assert int(np.asarray(Image.open(p))[2, 2, 0]) == 128
+    # one image: no border (make_grid returns it as is); single-channel input is repeated to RGB
+    U.save_grid(p, torch.full((1, 1, 3, 3), 1.0), 9)
+    one = np.asarray(Image.open(p))
+    assert one.shape == (3, 3, 3) and one.min() == 255
+    # the reference's sizes
+    assert tuple(U.make_grid(torch.zeros(27, 3, 128, 128), nrow=9, normalize=True, value_range=(-1, 1)).shape) == (3, 392, 1172)
+    assert tuple(U.make_grid(torch.zeros(2, 3, 128, 128), nrow=2, normalize=True, value_range=(-1, 1)).shape) == (3, 132, 262)
