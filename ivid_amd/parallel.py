@@ -85,6 +85,18 @@ def shard(seq, rank=None, world=None):
     return seq[rank::world]
 
 
+def shard_plan(num_samples, world, batchsize):
+    """What the rank-strided partition (sample.py:199-202) and sample_all's batching (sample.py:56-58: batches of `batchsize`,
+    the last one ragged) give every rank: [{rank, samples, batches, last_batch}].  BASELINE config 4: 10 000 samples on 8 ranks
+    in batches of 32 = 1250 samples per rank = 39 full batches + one batch of 2."""
+    plan = []
+    for r in range(world):
+        n = len(range(r, num_samples, world))
+        nb = (n + batchsize - 1) // batchsize
+        plan.append({"rank": r, "samples": n, "batches": nb, "last_batch": n - (nb - 1) * batchsize if nb else 0})
+    return plan
+
+
 def shard_views(modelviews, rank=None, world=None):
     """Per-sample camera lists are sharded, a shared camera list is not (sample.py:202)."""
     if modelviews and isinstance(modelviews[0], list):

@@ -28,8 +28,18 @@ class vec3:
 
 
 class mat4:
-    def __init__(self, m=None):
-        self.m = np.eye(4, dtype=np.float32) if m is None else np.asarray(m, np.float32).reshape(4, 4).copy()
+    def __init__(self, *a):
+        """mat4() identity; mat4(m) from a MATHEMATICAL 4x4 matrix (this module's own functions); mat4(16 scalars) in glm's
+        constructor order, i.e. column by column (PyGLM's `glm.mat4(x0, y0, z0, w0, x1, ...)`)."""
+        if len(a) == 16:
+            self.m = np.asarray(a, np.float32).reshape(4, 4).T.copy()
+        elif len(a) == 0 or a[0] is None:
+            self.m = np.eye(4, dtype=np.float32)
+        else:
+            self.m = np.asarray(a[0], np.float32).reshape(4, 4).copy()
+
+    def to_list(self):                  # PyGLM: list of COLUMNS
+        return [[float(v) for v in self.m[:, c]] for c in range(4)]
 
     def __array__(self, dtype=None, copy=None):
         return self.m if dtype is None else self.m.astype(dtype)

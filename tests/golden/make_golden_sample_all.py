@@ -13,6 +13,18 @@ oracle/glshim) -> the conditioning wiring of sample.py:99-120 -> conditional DDI
     present) or are restated (glm, cv2.erode: see oracle/glshim/glm.py, make_golden_warp.py).
 Models: the mini UNet at 128 x 128 (tests/common.py MINI128 / MINI128_COND; sample_all hard-wires 128), synthetic weights.
 Stores tests/golden/sample_all_ref.npz: the three views, the conditioning tensors handed to the conditional sampler.
+
+    python tests/golden/make_golden_sample_all.py          -> sample_all_ref.npz        (untrained weights: noise-like depth maps)
+    python tests/golden/make_golden_sample_all.py scene    -> sample_all_scene_ref.npz  (well-formed scenes)
+
+`scene`: untrained weights saturate the samples, the depth maps are noise and the conditioning masks of the next view are almost
+empty (0 % colour / 1.4 % depth coverage in sample_all_ref.npz) -- `replace_rgb` / `mask_rgb` / `constrain_depth` never act.
+For a fixture whose generated views are well-formed scenes, (1) the output convolution `out.2` of both synthetic checkpoints
+is scaled by 4e-6, so the predicted noise is a small texture instead of the whole signal, and (2) the three x_T draws
+(draw 0, 4 and 11 of the stream) are sqrt(alpha_bar_T) * (a smooth synthetic RGBD scene, tests/warp_common.py) + 4e-6 * (the
+stream's draw): DDIM's first x_0 prediction is then the scene plus texture (ddim.py:36-37).  Everything else -- the reference's
+sample_all, samplers, frameworks, renderer, shaders -- runs unchanged.  The generator ASSERTS mask coverage >= 50 % and
+mask_rgb >= 30 % on both conditional views, and also stores what aggregate_conditions returned (mask, mask_rgb, depth_convex).
 """
 import importlib.util
 import os
@@ -67,6 +79,11 @@ _mod("imageio")
 tv = _mod("torchvision")
 tv.utils = _mod("torchvision.utils")
 
+SCENE = len(sys.argv) > 1 and sys.argv[1] == "scene"
+XT_DRAWS = (0, 4, 11)          # positions of the three x_T draws in the stream (uncond: x_T + 3 step draws; cond view: x_T + 2 x 3)
+XT_NOISE, OUT_SCALE = 4e-6, 4e-6
+XT_BASE = {}                   # draw index -> tensor added to XT_NOISE * draw (filled below, scene mode)
+
 # ---- one seeded CPU noise stream for every draw, no CUDA ----
 GEN = torch.Generator(device="cpu")
 GEN.manual_seed(20260926)
@@ -81,6 +98,8 @@ def randn(*shape, **kw):
     if kw.get("generator") is not None:               # an explicit generator (oracle/synth.py's weights): not part of the stream
         return _randn(*shape, **kw)
     t = _randn(*shape, generator=GEN, dtype=kw.get("dtype", torch.float32))
+    if len(DRAWS) in XT_BASE:
+        t = XT_BASE[len(DRAWS)] + XT_NOISE * t
     DRAWS.append(tuple(t.shape))
     return t
 
@@ -103,7 +122,11 @@ torch.set_num_threads(os.cpu_count())
 
 def model(args, seed):
     m = rb.AdmUnet2d(**args).eval()
-    m.load_state_dict(C.synth_weights(args, seed), strict=True)
+    sd = C.synth_weights(args, seed)
+    if SCENE:
+        sd["out.2.weight"] = sd["out.2.weight"] * OUT_SCALE
+        sd["out.2.bias"] = sd["out.2.bias"] * OUT_SCALE
+    m.load_state_dict(sd, strict=True)
     return m
 
 
@@ -115,12 +138,41 @@ view_ids = [0, 3, 7]                                  # front, yaw +0.15, yaw -0
 views = [glm.lookAt(glm.vec3(np.sin(y) * np.cos(p), np.sin(p), np.cos(y) * np.cos(p)), glm.vec3(0, 0, 0), glm.vec3(0, 1, 0))
          for y, p in (vs[k] for k in view_ids)]        # inference/sample.py:331-335
 SU, SC, GUID, ERODE, CLS = 3, 2, 0.5, 1, [3]
+captured = []
+if SCENE:
+    xt_scale = float(fu.alphas_cumprod[-1]) ** 0.5          # both chains start at t = 999 (ddim.py:141-146)
+    for k, d in enumerate(XT_DRAWS):
+        XT_BASE[d] = xt_scale * torch.from_numpy(WC.synthetic_rgbd(128, 40 + k, smooth_color=True))
+    import rgbd_3d.utils as ref_utils
+    _agg = ref_utils.aggregate_conditions
+
+    def agg(*a, **kw):
+        c = _agg(*a, **kw)
+        captured.append({k: np.asarray(c[k]).copy() for k in ("color", "depth", "mask", "mask_rgb", "depth_convex")})
+        return c
+    ref_utils.aggregate_conditions = agg
+    ref_sample.rgbd_3d.utils.aggregate_conditions = agg
 out = list(ref_sample.sample_all(fu, fc, 1, SU, SC, views, classes=CLS, guidance=GUID, batchsize=1, erode_rgb=ERODE))
 meshes, colors, samples, conds = out[0]
 print("views", tuple(samples.shape), "conds", {k: tuple(v.shape) for k, v in conds.items()}, "draws", len(DRAWS))
 print("depth range of view 0 (in [-1,1]):", float(samples[0, 3].min()), float(samples[0, 3].max()))
-np.savez_compressed(os.path.join(HERE, "sample_all_ref.npz"), samples=samples.numpy().astype(np.float32),
+extra = {}
+name = "sample_all_ref.npz"
+if SCENE:
+    name = "sample_all_scene_ref.npz"
+    assert len(captured) == 2 and DRAWS[0] == DRAWS[4] == DRAWS[11] == (1, 4, 128, 128)
+    for j, c in enumerate(captured):
+        cov, cov_rgb = float(c["mask"].mean()), float(c["mask_rgb"].mean())
+        print(f"view {j + 1}: mask coverage {cov:.3f}, mask_rgb coverage {cov_rgb:.3f}")
+        assert cov >= 0.5 and cov_rgb >= 0.3, "the fixture must exercise the conditioning"
+        for k in ("mask", "mask_rgb"):
+            extra[f"cond_{k}"] = np.stack([cc[k] for cc in captured]).astype(np.uint8)
+        extra["cond_depth_convex"] = np.stack([cc["depth_convex"] for cc in captured]).astype(np.float32)
+    assert float(samples.abs().max()) <= 1.0 + 1e-6
+    extra.update(xt_scale=np.float64(xt_scale), xt_noise=np.float64(XT_NOISE), out_scale=np.float64(OUT_SCALE),
+                 xt_draws=np.array(XT_DRAWS), scene_seeds=np.array([40, 41, 42]))
+np.savez_compressed(os.path.join(HERE, name), **extra, samples=samples.numpy().astype(np.float32),
                     cond_color=conds["color"].numpy().astype(np.float32), cond_depth=conds["depth"].numpy().astype(np.float32),
                     view_ids=np.array(view_ids), cfg=np.array([SU, SC, ERODE]), guidance=np.array(GUID), classes=np.array(CLS),
                     draws=np.array([("x".join(map(str, d))) for d in DRAWS]), noise_seed=np.array(20260926))
-print("wrote sample_all_ref.npz", round(os.path.getsize(os.path.join(HERE, "sample_all_ref.npz")) / 1e6, 2), "MB")
+print("wrote", name, round(os.path.getsize(os.path.join(HERE, name)) / 1e6, 2), "MB")

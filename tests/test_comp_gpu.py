@@ -91,7 +91,8 @@ def test_conv2d_c_lo_planes(case, dtype):
     stats = torch.full((N * H * W // blk, Cout, 2), float("nan"), device="cuda") if (H * W) % blk == 0 else None
     d0, d1 = G.to_nhwc(x0, dtype), (G.to_nhwc(x1, dtype) if x1 is not None else None)
     wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
-    L.call("ivid_conv2d_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(b.cuda()), L.ptr(out), L.ptr(out_lo), L.ptr(rh),
+    bd = b.cuda()                     # device tensors stay referenced until the launch has finished
+    L.call("ivid_conv2d_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(out_lo), L.ptr(rh),
            L.ptr(rl), res_mode, 0, N, H, W, Cout, k * k, tile, L.ptr(stats), G.stream())
     torch.cuda.synchronize()
     got = joined(out, out_lo)
@@ -172,7 +173,8 @@ def test_conv3x3_gn_skip_c_lo_planes(case, dtype):
     d0, d1 = G.to_nhwc(x0, dtype), (G.to_nhwc(x1, dtype) if x1 is not None else None)
     ab = torch.stack([a, b], -1).contiguous().cuda()
     wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
-    L.call("ivid_conv3x3_gn_skip_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), 0, L.ptr(wp), L.ptr(bias.cuda()), L.ptr(out),
+    bd = bias.cuda()
+    L.call("ivid_conv3x3_gn_skip_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out),
            L.ptr(out_lo), L.ptr(rh), L.ptr(rl), res_mode, N, H, W, Cout, L.ptr(stats), L.ptr(sk0), S0, L.ptr(sk1), S1, L.ptr(wsk),
            G.stream())
     torch.cuda.synchronize()
@@ -248,12 +250,13 @@ def test_conv3x3_gn_out_c_split_head(dtype, shape):
     wlo = (w2 - whi.float()).to(t)
     out = torch.full((N, Cout, H, W), float("nan"), device="cuda")
     ab = torch.stack([a, b], -1).contiguous().cuda()
-    L.call("ivid_conv3x3_gn_out_c", dtype, L.ptr(xh), L.ptr(xl), Cc, L.ptr(ab), L.ptr(whi.cuda()), L.ptr(wlo.cuda()), L.ptr(bias.cuda()),
+    whd, wld, bd = whi.cuda(), wlo.cuda(), bias.cuda()
+    L.call("ivid_conv3x3_gn_out_c", dtype, L.ptr(xh), L.ptr(xl), Cc, L.ptr(ab), L.ptr(whd), L.ptr(wld), L.ptr(bd),
            L.ptr(out), N, H, W, Cout, G.stream())
     torch.cuda.synchronize()
     e = common.rel_l2(out.cpu(), ref)
     out1 = torch.empty_like(out)
-    L.call("ivid_conv3x3_gn_out", dtype, L.ptr(xh), Cc, L.ptr(ab), L.ptr(whi.cuda()), L.ptr(bias.cuda()), L.ptr(out1), N, H, W, Cout,
+    L.call("ivid_conv3x3_gn_out", dtype, L.ptr(xh), Cc, L.ptr(ab), L.ptr(whd), L.ptr(bd), L.ptr(out1), N, H, W, Cout,
            G.stream())
     torch.cuda.synchronize()
     e1 = common.rel_l2(out1.cpu(), ref)
@@ -281,10 +284,11 @@ def test_stem_split_reproduces_the_unrounded_convolution(dtype, cin):
     wlo = (w2 - whi.float()).to(t)
     w3 = F.pad(torch.cat([whi, whi, wlo], 1), (0, Kpad - 3 * K9)).contiguous().cuda()
     col = torch.full((N, H, W, Kpad), float("nan"), device="cuda", dtype=t)
-    L.call("ivid_stem_im2col_split", dtype, L.ptr(x.cuda()), Bsrc, N, cin, H, W, Kpad, L.ptr(col), G.stream())
+    xd, bd = x.cuda(), bias.cuda()
+    L.call("ivid_stem_im2col_split", dtype, L.ptr(xd), Bsrc, N, cin, H, W, Kpad, L.ptr(col), G.stream())
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=t)
     out_lo = torch.full_like(out, float("nan"))
-    L.call("ivid_conv2d_c", dtype, L.ptr(col), Kpad, None, 0, L.ptr(w3), L.ptr(bias.cuda()), L.ptr(out), L.ptr(out_lo), None, None, 0, 0,
+    L.call("ivid_conv2d_c", dtype, L.ptr(col), Kpad, None, 0, L.ptr(w3), L.ptr(bd), L.ptr(out), L.ptr(out_lo), None, None, 0, 0,
            N, H, W, Cout, 1, 0, None, G.stream())
     torch.cuda.synchronize()
     assert torch.isfinite(col.float()).all()

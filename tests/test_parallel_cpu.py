@@ -138,3 +138,48 @@ def test_bad_checkpoint_raises_on_every_rank_instead_of_hanging():
         assert p.exitcode == 0
     assert "missing ['time_embed.1.bias']" in res[0] and "not.a.parameter" in res[0] and "out.2.bias" in res[0]
     assert "rejected the checkpoint" in res[1]
+
+
+def _c4_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, C.ROOT)
+    from ivid_amd import parallel
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_from_env("gloo")
+    seeds = list(range(10000))
+    mine = parallel.shard(seeds)
+    batches = [mine[i:i + 32] for i in range(0, len(mine), 32)]            # sample_all's batching (sample.py:56-58)
+    secs = parallel.gather_scalars(100.0 + rank)                            # per-rank clocks as bench.py --config c4 reports them
+    seed = parallel.common_draw_seed()                                      # one seed for the draws all ranks must share
+    q.put((rank, len(mine), len(batches), len(batches[-1]), mine[:2], mine[-1], secs, seed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_shard_arithmetic_world_size_8_with_the_ragged_last_batch():
+    """BASELINE config 4: 10 000 samples sharded over 8 ranks (seeds[rank::8], sample.py:199-202) in batches of 32: every
+    rank gets 1250 samples = 39 full batches + ONE batch of 2.  Dry run over gloo with 8 processes: the shards are a disjoint
+    cover, the plan bench.py prints matches what the ranks really get, per-rank timings and the common draw seed arrive
+    everywhere."""
+    from ivid_amd import parallel
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_c4_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    plan = parallel.shard_plan(10000, 8, 32)
+    for r, (rank, n, nb, last, first2, lastseed, secs, seed) in enumerate(res):
+        assert rank == r and (n, nb, last) == (1250, 40, 2) == (plan[r]["samples"], plan[r]["batches"], plan[r]["last_batch"])
+        assert first2 == [r, r + 8] and lastseed == 9992 + r
+        assert secs == [100.0 + k for k in range(8)]
+        assert seed == res[0][7]
+    assert sum(p["samples"] for p in plan) == 10000
+    # ragged totals: 10 001 samples leave rank 0 one more sample; a world that does not divide the batch count
+    p2 = parallel.shard_plan(10001, 8, 32)
+    assert [p["samples"] for p in p2] == [1251] + [1250] * 7 and p2[0]["last_batch"] == 3
+    assert parallel.shard_plan(5, 8, 32)[5] == {"rank": 5, "samples": 0, "batches": 0, "last_batch": 0}

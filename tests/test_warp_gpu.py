@@ -525,3 +525,41 @@ def test_product_equals_real_opengl_on_load_scene_meshes_and_along_the_autoregre
         mesh.modelview = mv
         ms.append(mesh)
         cs.append(np.ascontiguousarray(hw[:, :, :3]))
+
+
+def test_product_scene_file_rendered_by_the_references_own_render_py():
+    """tests/golden/make_golden_render.py: tests/golden/scene_product.npz was WRITTEN by the product's save_scene (three generated
+    views + cameras) and CONSUMED by the reference's own inference/render.py, executed unchanged in the build container -- its
+    load_scene decoded the file and re-meshed it (depth_to_mesh, padding 32), its AggregationRenderer rendered the swing
+    trajectory at SSAA 5 on real OpenGL, its post-processing produced the frames of tests/golden/render_ref.npz.  Here the same
+    file goes through ivid_amd.inference.render: the frames must agree (8-bit colour after LANCZOS, inferno-coloured depth)."""
+    import os
+    from ivid_amd import rgbd_3d
+    from ivid_amd.inference import render as R, utils as U
+    g = C.load_golden("render_ref")
+    path = os.path.join(C.GOLDEN, "scene_product.npz")
+    scene = U.read_scene(path)
+    assert len(scene) == 3 and scene[0]["color"].shape == (128, 128, 3)
+    # the committed file IS what the product writes: re-writing the same views gives the same decoded content
+    gs = C.load_golden("sample_all_scene_ref")
+    vs = WC.viewset_3x9()
+    mvs = [WC.orbit(*vs[int(k)]) for k in gs["view_ids"]]
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        U.save_scene(os.path.join(tmp, "again.npz"), torch.from_numpy(gs["samples"]), mvs, 45, 0.6, 5)
+        again = U.read_scene(os.path.join(tmp, "again.npz"))
+    for a, b in zip(scene, again):
+        assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+        assert np.allclose(a["modelview"], b["modelview"], atol=1e-7) and a["fov"] == b["fov"]
+    frames = int(g["frames"])
+    rr = rgbd_3d.WarpRenderer(1, 128, 5, 27, near=0.1, far=200.0)
+    colors, depths = R.render_scene(rr, scene, R.trajectory("swing", frames, 1), 0.03, 0.03, 3, 5)
+    assert colors.shape == g["colors"].shape and depths.shape == g["depths"].shape
+    dc = np.abs(colors.astype(int) - g["colors"].astype(int)).max(-1)
+    dd = np.abs(depths.astype(int) - g["depths"].astype(int)).max(-1)
+    errs = dict(color_frac_within_2=float((dc <= 2).mean()), color_frac_within_8=float((dc <= 8).mean()), color_mean_abs=float(dc.mean()),
+                depth_frac_within_3=float((dd <= 3).mean()), frames=frames)
+    G.report("warp/render_py_on_product_scene", **errs)
+    print("reference render.py vs ivid_amd.inference.render", errs)
+    # silhouette pixels where a z tie / sub-pixel coverage differs survive LANCZOS as a few levels: the bulk must match
+    assert errs["color_frac_within_2"] > 0.97 and errs["color_frac_within_8"] > 0.995 and errs["depth_frac_within_3"] > 0.98, errs
