@@ -160,7 +160,7 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
                          int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
                          const void* skip_weight, void* stream);
 
-/* ivid_conv3x3_gn_skip with the lo planes of the output / residual source (see ivid_conv2d_c); Cout > 128 only. */
+/* ivid_conv3x3_gn_skip with the lo planes of the output / residual source (see ivid_conv2d_c). */
 int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                            const void* weight, const float* bias, void* out, void* out_lo, const void* res, const void* res_lo,
                            int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0, int skipC0,

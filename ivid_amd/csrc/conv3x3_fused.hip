@@ -793,12 +793,11 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const
         (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
-  if ((out_lo || res_lo) && (esz != 2 || narrow))
-    return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype and Cout > 128", hipSuccess);
+  if ((out_lo || res_lo) && esz != 2) return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype", hipSuccess);
   if (res_lo && !res_mode) return ivid_set_error("conv3x3_gn: res_lo without a residual", hipSuccess);
   if (narrow)
     return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, skip0,
-                                skipC0, skip1, skipC1, skip_weight, stream);
+                                skipC0, skip1, skipC1, skip_weight, stream, out_lo, res_lo);
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;

@@ -42,6 +42,9 @@ struct FusedArgs {
   const char* sk1;
   const char* skw;     // [Cout][skC0+skC1]
   int skC0, skC1;
+  // compensated 16-bit storage (precision mode fp16c, see conv_igemm.hip ConvArgs): optional lo planes of the output / residual
+  char* out_lo;
+  const char* res_lo;
 };
 
 constexpr int TH = 16, TW = 32;            // output tile (pixels)
@@ -60,7 +63,7 @@ constexpr int PIECES = (HROWS + 127) / 128; // halo pieces per thread (128 halo 
 constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 114,304
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <typename T>
+template <typename T, bool LO = false>
 __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -424,6 +427,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
   // (fp32 storage: 8 pieces per lane and fragment -- batching four fragments would spill, so those modes prefetch per fragment)
   constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
   vec_t rres[HB][NPS];
+  vec_t rres_lo[LO ? HB : 1][LO ? NPS : 1];
+  const bool res_has_lo = LO && p.res_lo != nullptr;
+  const bool out_has_lo = LO && p.out_lo != nullptr;
   auto load_res = [&](int mi) {
     const int y = y0 + wm * 4 + mi;
 #pragma unroll
@@ -432,6 +438,9 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
       const size_t pix = p.res_mode == 1 ? ((size_t)img * p.H + y) * p.W + xr
                                          : ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (xr >> 1);
       rres[mi % HB][ps] = *(const vec_t*)(p.res + (pix * Cout + nbase + lc) * sizeof(T));
+      if constexpr (LO) {
+        if (res_has_lo) rres_lo[mi % HB][ps] = *(const vec_t*)(p.res_lo + (pix * Cout + nbase + lc) * sizeof(T));
+      }
     }
   };
   const bool res12 = (p.res_mode == 1 || p.res_mode == 2) && nbase + lc < Cout;
@@ -487,6 +496,14 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
         if (p.res_mode == 1 || p.res_mode == 2) {
           float rv[VE];
           vec_to_f32<T>(rres[mi % HB][ps], rv);
+          if constexpr (LO) {
+            if (res_has_lo) {
+              float rl[VE];
+              vec_to_f32<T>(rres_lo[mi % HB][ps], rl);
+#pragma unroll
+              for (int e = 0; e < VE; ++e) rv[e] += rl[e];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += rv[e];
         } else if (p.res_mode == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)
@@ -500,15 +517,34 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
             vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
 #pragma unroll
             for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
+            if constexpr (LO) {
+              if (res_has_lo) {
+                vec_to_f32<T>(*(const vec_t*)(p.res_lo + (pix * Cout + n) * sizeof(T)), rv);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
+              }
+            }
           }
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
         }
         const vec_t ov = f32_to_vec<T>(v);
         *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+        float sv[VE];
+        vec_to_f32<T>(ov, sv);
+        if constexpr (LO) {
+          if (out_has_lo) {   // lo plane: what the 16-bit rounding dropped; the statistics describe hi + lo
+            float lv[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) lv[e] = v[e] - sv[e];
+            const vec_t ol = f32_to_vec<T>(lv);
+            *(vec_t*)(p.out_lo + (m * Cout + n) * sizeof(T)) = ol;
+            vec_to_f32<T>(ol, lv);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) sv[e] += lv[e];
+          }
+        }
         if (p.stats) {
-          float sv[VE];
-          vec_to_f32<T>(ov, sv);
 #pragma unroll
           for (int e = 0; e < VE; ++e) {
             st_s[e] += sv[e];
@@ -539,8 +575,8 @@ __global__ __launch_bounds__(NT) void conv3x3_fused128_kernel(const FusedArgs p)
   }
 }
 
-template <typename T> int launch_fused128(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused128_kernel<T>;
+template <typename T, bool LO = false> int launch_fused128(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused128_kernel<T, LO>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -566,7 +602,7 @@ bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout, i
 int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                          const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
                          int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
-                         const void* skip_weight, void* stream) {
+                         const void* skip_weight, void* stream, void* out_lo, const void* res_lo) {
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;
@@ -575,6 +611,11 @@ int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, 
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
+  a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo;
+  if (out_lo || res_lo) {
+    if (dtype == IVID_BF16) return launch_fused128<__bf16, true>(a, (hipStream_t)stream);
+    return launch_fused128<_Float16, true>(a, (hipStream_t)stream);
+  }
   if (dtype == IVID_BF16) return launch_fused128<__bf16>(a, (hipStream_t)stream);
   if (dtype == IVID_F16) return launch_fused128<_Float16>(a, (hipStream_t)stream);
   return launch_fused128<float>(a, (hipStream_t)stream);

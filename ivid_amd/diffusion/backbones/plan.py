@@ -383,7 +383,7 @@ class UNetPlan:
         so = op.res_out
         # Cout > 128: the 8x32x256 fused kernel.  Cout <= 128 (the small / SR models' first levels): its 16x32x128 variant
         # with 64-byte chunks (csrc/conv3x3_fused128.hip; not for bf16x3, which keeps gn_apply + igemm there)
-        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and not self.comp and so % 32 == 0
+        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and so % 32 == 0
         fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         h1 = self._new(n, so, op.cout, stats=True)

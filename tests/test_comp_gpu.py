@@ -135,6 +135,11 @@ FUSED_C = [
     ("down_res_avgpool_c160", 2, 16, 32, 64, 0, 160, 3, (0, 0)),
     ("concat_nores_c320", 1, 8, 64, 64, 64, 320, 0, (0, 0)),
     ("skip_cat_128+64_c192", 2, 16, 32, 64, 0, 192, 0, (128, 64)),
+    # Cout <= 128 and H % 16 == 0: the 16x32x128 variant (csrc/conv3x3_fused128.hip)
+    ("n128_same_res_c128", 2, 32, 32, 128, 0, 128, 1, (0, 0)),
+    ("n128_up_res_c96tail", 2, 32, 64, 64, 0, 96, 2, (0, 0)),
+    ("n128_down_res_avgpool_c64", 3, 16, 32, 64, 0, 64, 3, (0, 0)),
+    ("n128_skip_cat_128+128_c128", 2, 32, 32, 128, 0, 128, 0, (128, 128)),
 ]
 
 
