@@ -163,7 +163,8 @@ def test_oracle_render_equals_the_references_renderer_on_real_opengl(tag):
     aggregation + resolve of the oracle must reproduce it: this pins the warp oracle -- against which the HIP kernels are
     checked at every size -- to an actual OpenGL implementation.  Scenes: two views, three views with two depth layers, the
     full `3x9` viewset (26 source views), a camera inside the scene (512 triangles clipped at the near plane), white-noise
-    depth (everything low-confidence), an SSAA-5 free-view frame, and a full-size 128^2 pair at 384^2."""
+    depth (everything low-confidence), an SSAA-5 free-view frame, a full-size 128^2 pair at 384^2, and (round 3) the FULL 26-view
+    `3x9` aggregation and a three-view layered scene at full size (128^2 views, 384^2 target)."""
     g = C.load_golden("warp_gl")
     tag_, S, ssaa, near, far, views, target = next(s for s in WC.gl_scenes() if s[0] == tag)
     meshes, cols = zip(*[WC.oracle_mesh(WC.synthetic_rgbd(S, seed, layers=layers)[0], mv) for mv, seed, layers in views])

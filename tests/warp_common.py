@@ -64,6 +64,11 @@ def gl_scenes():
         ("free_view_ssaa5_S32", 32, 5, 0.1, 200.0, [(orbit(0.0, 0.0), 70, False), (orbit(-0.3, 0.0), 71, True)],
          orbit(0.6 * np.cos(1.0), 0.15 * np.sin(1.0))),
         ("full_size_S128", 128, 3, 0.01, 200.0, [(orbit(0.0, 0.0), 80, False), (orbit(0.0, 0.15), 81, False)], orbit(0.15, -0.15)),
+        # round 3: the FULL `3x9` aggregation at the size the sampler runs it (26 stored views of 128^2, 384^2 render target:
+        # the conditioning of the 27th view, sample.py:87-98) and a full-size layered scene seen from the far side
+        ("viewset_3x9_S128", 128, 3, 0.01, 200.0, [(orbit(*vs[v]), 200 + v, v % 3 == 1) for v in range(26)], orbit(*vs[26])),
+        ("wide_layers_S128", 128, 3, 0.01, 200.0,
+         [(orbit(0.0, 0.0), 90, False), (orbit(-0.3, 0.15), 91, True), (orbit(0.6, 0.0), 92, False)], orbit(-0.6, -0.15)),
     ]
     return sc
 
