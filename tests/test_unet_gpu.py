@@ -307,6 +307,26 @@ def test_fp16c_keeps_the_trunk_as_hi_plus_lo_planes():
     assert not [n for _, n, _ in m2.plan(2, False).launches if n.endswith("_c") or n.endswith("_split")]
 
 
+@pytest.mark.parametrize("precision", ["fp16c", "fp16"])
+def test_16bit_forward_is_bitwise_batch_invariant(precision):
+    """The sharding invariant in the headline precision: a sample's output must not depend on the batch it is computed in (ranks
+    get different batch sizes: ragged last batches, `seeds[rank::world]`).  Statistics blocks, summation orders and the hi / lo
+    split are per sample, so the result is BIT-identical for batch 5, batch 2 and batch 1, stacked CFG or not."""
+    m, _ = build(C.MINI, 0, precision)
+    x = C.seeded_randn(5, 5, 4, 32, 32).cuda()
+    t = torch.full((5,), 400, dtype=torch.long).cuda()
+    cls = torch.tensor([1, 2, 3, 4, 5]).cuda()
+    ec, eu = m.forward_cfg(x, t, cls)
+    ec, eu = ec.clone(), eu.clone()
+    for i in (0, 3, 4):
+        c1, u1 = m.forward_cfg(x[i:i + 1], t[i:i + 1], cls[i:i + 1])
+        assert torch.equal(c1[0], ec[i]) and torch.equal(u1[0], eu[i]), (precision, i)
+    c2, u2 = m.forward_cfg(x[1:3], t[1:3], cls[1:3])
+    assert torch.equal(c2, ec[1:3]) and torch.equal(u2, eu[1:3])
+    plain = m(x[2:4], t[2:4], cls[2:4])                      # not stacked: the class-independent prefix is computed per row
+    assert torch.equal(plain, ec[2:4])
+
+
 def test_sr256_forward_and_superres_chain_match_oracle():
     """BASELINE config 5's model (SR 128->256: 8 input channels, attention at T = 4096 / 1024 / 256): one fp32 forward
     against the oracle on the host, and SuperResCFG + DDIM through `super_resolve` on the 64-px mini variant."""
