@@ -8,6 +8,7 @@ at a time, on the large-128 synthetic checkpoint of tests/golden/large128_fwd.np
     H  inner storage: the in_layers conv output h1 rounded
     B  compensated trunk (fp16 hi + lo planes): branch inputs (GroupNorm -> conv, 1x1 skip conv, attention norm) see the
        rounded hi plane, residual adds and the stored trunk are exact
+    N  the attention block's GroupNorm reads the hi plane alone (gn_apply without the lo plane)
     Q  attention internals: normalised input, qkv, softmax probabilities, attention output rounded
 Prints rel-L2 vs the committed reference output for: all on, each one alone, each one removed.
 
@@ -68,7 +69,7 @@ def attnblock(sd, p, x, head_channels, groups, q):
     q.side = hh
     q.blk = p
     xf = x.reshape(b, c, -1)
-    xn = q("Q", O.gn32(q("B", xf), sd[p + ".norm.weight"], sd[p + ".norm.bias"], groups))
+    xn = q("Q", O.gn32(q("N", q("B", xf)), sd[p + ".norm.weight"], sd[p + ".norm.bias"], groups))
     qkv = q("Q", F.conv1d(xn, q("W", sd[p + ".qkv.weight"]), sd[p + ".qkv.bias"]))
     heads = c // head_channels
     bb, width, t = qkv.shape
