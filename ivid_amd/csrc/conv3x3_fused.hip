@@ -87,8 +87,9 @@ constexpr int PIECES = (HROWS + 63) / 64;  // halo pieces per thread (64 halo pi
 constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 163,456 of the CU's 163,840
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-template <typename T, bool LO = false>
-__global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
+// One output tile (8 x 32 pixels x 256 output channels) of the launch: the whole kernel body.  `tile` is the logical tile id.
+template <typename T, bool LO>
+__device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
   constexpr int BKE = 128 / (int)sizeof(T);
@@ -100,7 +101,6 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
 
   TL_STAMP(0);
   TL_STAMP(1);
-  const int tile = xcd_remap(blockIdx.x, p.ntiles_total);
   // tile id -> (image, tile row, tile col, cout tile); cout tiles of one pixel tile are neighbours (shared A in L2)
   const int tn = tile % p.ntiles_n;
   int rest = tile / p.ntiles_n;
@@ -746,6 +746,15 @@ __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
     p.dbg[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |       // HW_ID
                                         ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); // XCC_ID
 #endif
+}
+
+// (Measured and dropped, round 3: a PERSISTENT form -- one workgroup per CU looping over its share of the tiles, the XCD's
+// range walked side by side -- is bit-identical and 1.5-3 % slower on every layer (128^2 256->256: 1011 vs 1027 TF/s, 512->256:
+// 1199 vs 1218): the barrier between tiles and ~100 scalar spills of the hoisted launch constants cost more than the
+// workgroup dispatch it saves.)
+template <typename T, bool LO = false>
+__global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
+  fused_tile<T, LO>(p, xcd_remap(blockIdx.x, p.ntiles_total));
 }
 
 template <typename T, bool LO = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
