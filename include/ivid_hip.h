@@ -12,7 +12,9 @@
  *   - activations inside the UNet are NHWC ("pixel-major") of dtype IVID_F32 (parity mode, exact
  *     fp32 MFMA), IVID_BF16 / IVID_F16 (16-bit storage and MFMA operands, fp32 accumulate) or
  *     IVID_BF16X3 (fp32 storage, split-bf16 MFMA); the model boundary is fp32 NCHW exactly like the
- *     reference (adm.py:557,565-566).
+ *     reference (adm.py:557,565-566).  Precision mode "fp16c" of the Python surface is IVID_F16 plus the `*_c` / `*_split`
+ *     entry points below: tensors of the residual stream carry a second 16-bit plane (compensated storage, see
+ *     ivid_conv2d_c), which keeps one forward within 1e-3 of the reference's fp32 path at the fp16 MFMA rate.
  */
 #ifndef IVID_HIP_H
 #define IVID_HIP_H
