@@ -25,3 +25,15 @@ def uniform_timestep(t):
 
 def as_f32(t):
     return t.float().contiguous()
+
+
+def framework_eps(framework, x_t, t_model, classes, kwargs):
+    """-> (eps_cond, eps_uncond | None, strength) for the fused step kernels.  Frameworks of this package expose `eps_branches`
+    (both guidance branches out of ONE stacked forward, combined inside the step kernel).  Any other object with the
+    reference's framework contract -- `model_inference(x, t, classes=..., **kwargs) -> eps` (gaussian_diffusion.py:56-70,
+    classifier_free_guidance.py:23-42) -- is called exactly as the reference's samplers call it (ddim.py:81, ddpm.py:101) and
+    its already combined eps passes through the kernel unchanged."""
+    if hasattr(framework, "eps_branches"):
+        return framework.eps_branches(x_t, t_model, classes=classes, **kwargs)
+    kw = {k: v for k, v in kwargs.items() if k != "noise_fn"}      # noise_fn is this package's sampler option, not the framework's
+    return framework.model_inference(x_t, t_model, classes=classes, **kw), None, 0.0

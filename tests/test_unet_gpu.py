@@ -407,6 +407,35 @@ def test_full_size_properties_large_bf16_bs64():
     G.report("unet/large128_bs64_bf16", golden_row_rel_l2=C.rel_l2(e, g["eps"]))
 
 
+def test_samplers_accept_a_foreign_framework_with_the_reference_contract():
+    """The samplers take any framework object with the reference's contract -- `.backbone`, `.betas`, `.timesteps`,
+    `model_inference(x, t, classes=..., **kwargs) -> eps` (gaussian_diffusion.py:31-70) -- not only this package's classes (which add
+    `eps_branches`): such a framework is called as the reference's samplers call it (ddim.py:81, ddpm.py:101)."""
+    from ivid_amd.diffusion import frameworks, samplers
+    m, _ = build(C.MINI, 0, "fp32")
+    own = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+
+    class Foreign:                                    # what a user of the reference might bring: no eps_branches
+        def __init__(self, fw):
+            self.backbone, self.betas, self.timesteps, self._fw = fw.backbone, fw.betas, fw.timesteps, fw
+
+        def model_inference(self, x, t, classes=None, strength=3.0, **kwargs):
+            assert "noise_fn" not in kwargs
+            return self._fw.model_inference(x, t, classes=classes, strength=strength)
+    x_T = C.seeded_randn(11, 2, 4, 32, 32).cuda()
+    cls = torch.tensor([1, 5]).cuda()
+    res = {}
+    for name, fw in (("own", own), ("foreign", Foreign(own))):
+        torch.manual_seed(5)
+        r = samplers.DdimSampler(fw).sample(2, noise=x_T, classes=cls, steps=4, eta=0.5, strength=0.5, verbose=False,
+                                            noise_fn=_cpu_noise_fn())
+        torch.manual_seed(6)
+        p = samplers.DdpmSampler(fw).sample_once(x_T, 500, cls, strength=0.5, noise_fn=_cpu_noise_fn())
+        res[name] = (r.samples.cpu(), p.pred_x_prev.cpu(), p.pred_x_0.cpu())
+    for a, b in zip(res["foreign"], res["own"]):
+        assert C.rel_l2(a, b) < 1e-5       # same arithmetic; the CFG combine runs in the framework instead of the step kernel
+
+
 def test_edge_batches_empty_and_single():
     """Ragged / degenerate batches: an empty batch returns an empty fp32 tensor like the reference's torch ops would, a
     batch of one matches the oracle (tile tails everywhere: 1 image = 4 tiles of the fused kernel at 32^2)."""
