@@ -17,7 +17,7 @@ Headline precision (`--precision auto`, the default): the FASTEST mode that is i
 (outputs within 1e-3 of the reference's fp32 CPU path) on BOTH checks -- the deviation of one large-model forward from the
 committed output of the live reference, measured in this run, and the deviation of the BASELINE-config-2 chain itself
 (50-step DDIM + CFG 0.5, tests/golden/large128_ddim50_cfg.npz) as measured by the GPU test and committed under
-profiles/ (`chain_parity`).  Candidates in speed order: bf16, fp16, fp16c, bf16x3.  The modes that are faster but outside
+profiles/ (`chain_parity`).  Candidates in speed order: bf16, fp16, fp16c, fp16cx, bf16x3.  The modes that are faster but outside
 the tolerance are timed beside it in `other_modes` with their deviations; they are not `value`.
 
 Prints ONE JSON line (rank 0).  Extra objects:
@@ -44,15 +44,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
 # flops (its 3 MFMAs per product are overhead, not work)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
-DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2}
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2}
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
 PARITY_TOL = 1e-3                                           # BASELINE.json north_star: outputs within 1e-3 of the reference
-SPEED_ORDER = ["bf16", "fp16", "fp16c", "bf16x3"]           # fastest first (measured: profiles/r03_*)
+SPEED_ORDER = ["bf16", "fp16", "fp16c", "fp16cx", "bf16x3"]  # fastest first (measured: profiles/r03_*)
 
 
 def committed_chain_parity(model_name):
@@ -85,7 +85,7 @@ def parse_args(argv=None):
                     help="auto: the fastest mode within 1e-3 of the reference (forward measured in-run + committed chain figure)")
     ap.add_argument("--parity-precision", default="bf16x3", choices=sorted(DTYPE_CODE),
                     help="second, parity-grade mode timed beside the headline ('none' via --no-parity-mode)")
-    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c",
+    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c,fp16cx",
                     help="comma list of further modes timed briefly beside the headline (fp16 = the reference's use_fp16 torso)")
     ap.add_argument("--guidance", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,10 +210,12 @@ def canonical_launch(name, args):
         extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
         return "ivid_conv2d", tuple(a for i, a in enumerate(args) if i not in (8, 10)), float(extra)
     if name == "ivid_conv3x3_gn_skip_c":
-        dt, rm, n, h, w, cout = args[0], args[13], args[14], args[15], args[16], args[17]
+        (dt, _s0, s0lo, c0, _s1, s1lo, c1, _ab, up, _w, _b, _o, olo, _r, rlo, rm, n, h, w, cout) = args[:20]
         plane = n * h * w * cout * ESZ[dt]
-        extra = (plane if args[10] else 0) + (0 if not args[12] else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
-        return "ivid_conv3x3_gn_skip", tuple(a for i, a in enumerate(args) if i not in (10, 12)), float(extra)
+        src_px = n * (h >> up) * (w >> up) * ESZ[dt]
+        extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
+        extra += (src_px * c0 if s0lo else 0) + (src_px * c1 if s1lo else 0)
+        return "ivid_conv3x3_gn_skip", tuple(a for i, a in enumerate(args) if i not in (2, 5, 12, 14)), float(extra)
     if name == "ivid_conv3x3_gn_out_c":
         (dt, src, slo, c, ab, w, _wlo, b, o, n, h, w_, co) = args
         return "ivid_conv3x3_gn_out", (dt, src, c, ab, w, b, o, n, h, w_, co), float(n * h * w_ * c * ESZ[dt] if slo else 0)
@@ -474,7 +476,7 @@ def main():
         # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
         # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
         # profiles/r01_mfma_power.txt) -- the ceiling this kernel actually works under:
-        if a.precision in ("bf16", "fp16", "fp16c") and dom["bound"] == "mfma":
+        if a.precision in ("bf16", "fp16", "fp16c", "fp16cx") and dom["bound"] == "mfma":
             dom["power_limited_mfma_peak_random_operands"] = 1606.0
             dom["frac_of_power_limited_peak"] = round(dom["achieved"] / 1606.0, 4)
         result["roofline"] = dom

@@ -162,11 +162,13 @@ int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, 
                          int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
                          const void* skip_weight, void* stream);
 
-/* ivid_conv3x3_gn_skip with the lo planes of the output / residual source (see ivid_conv2d_c). */
-int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
-                           const void* weight, const float* bias, void* out, void* out_lo, const void* res, const void* res_lo,
-                           int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0, int skipC0,
-                           const void* skip1, int skipC1, const void* skip_weight, void* stream);
+/* ivid_conv3x3_gn_skip with lo planes (see ivid_conv2d_c): of the output and the residual source, and of the two convolution
+ * INPUTS -- the halo transform then starts from hi + lo (the block input `x` of `in_layers`, adm.py:203, and `h` of `out_layers`,
+ * adm.py:214-219, enter GroupNorm unrounded); the 1x1 skip phase reads the hi planes (they are the MFMA operand).  NULL = none. */
+int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1,
+                           const float* ab, int up, const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                           const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0,
+                           int skipC0, const void* skip1, int skipC1, const void* skip_weight, void* stream);
 
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].

@@ -54,10 +54,13 @@ struct FusedArgs {
   const char* sk1;
   const char* skw;     // [Cout][skC0+skC1]
   int skC0, skC1;
-  // compensated 16-bit storage (precision mode fp16c, see conv_igemm.hip ConvArgs): optional lo planes of the output and
-  // of the residual source; only the LO instantiation of the kernel looks at them
+  // compensated 16-bit storage (precision mode fp16c, see conv_igemm.hip ConvArgs): optional lo planes of the output, of
+  // the residual source and of the two convolution inputs (the halo transform then starts from hi + lo; the 1x1 skip
+  // phase reads the hi planes: they are the MFMA operand); only the LO instantiation of the kernel looks at them
   char* out_lo;
   const char* res_lo;
+  const char* src0_lo;
+  const char* src1_lo;
 #ifdef IVID_DEV_TIMELINE
   unsigned long long* dbg;             // [blocks][8] phase time stamps (scripts/dev/fused_timeline.py)
 #endif
@@ -88,7 +91,8 @@ constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;  // 163,456 of the CU's 163
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // One output tile (8 x 32 pixels x 256 output channels) of the launch: the whole kernel body.  `tile` is the logical tile id.
-template <typename T, bool LO>
+// LO: output / residual lo planes in the epilogue.  LOIN: the halo transform reads lo planes of the inputs as well.
+template <typename T, bool LO, bool LOIN>
 __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -142,16 +146,30 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   const size_t img_px = (size_t)img * Hs * Ws;
   const char* const src0_img = p.src0 + img_px * p.C0 * sizeof(T);
   const char* const src1_img = p.src1 + img_px * p.C1 * sizeof(T);
-  struct ChunkSrc { const char* base; int cb; };  // cb = bytes per source pixel
+  // LO: every halo piece is fetched from the lo plane as well.  A source without one is given its own hi plane as a
+  // stand-in with weight 0: the number of memory operations per issue window stays a compile-time constant (the counted
+  // vmcnt waits of the main loop depend on it).
+  const char* const lo0_img = LOIN ? (p.src0_lo ? p.src0_lo : p.src0) + img_px * p.C0 * sizeof(T) : nullptr;
+  const char* const lo1_img = LOIN ? (p.src1_lo ? p.src1_lo : p.src1) + img_px * p.C1 * sizeof(T) : nullptr;
+  struct ChunkSrc { const char* base; const char* lo; float lw; int cb; };  // cb = bytes per source pixel; lw: weight of the lo piece
   auto chunk_src = [&](int ch) -> ChunkSrc {
     const int cbase = ch * BKE;
     ChunkSrc c;
-    if (cbase >= p.C0) { c.base = src1_img + (size_t)(cbase - p.C0) * sizeof(T); c.cb = p.C1 * (int)sizeof(T); }
-    else               { c.base = src0_img + (size_t)cbase * sizeof(T); c.cb = p.C0 * (int)sizeof(T); }
+    c.lo = nullptr; c.lw = 0.f;
+    if (cbase >= p.C0) {
+      c.base = src1_img + (size_t)(cbase - p.C0) * sizeof(T); c.cb = p.C1 * (int)sizeof(T);
+      if constexpr (LOIN) { c.lo = lo1_img + (size_t)(cbase - p.C0) * sizeof(T); c.lw = p.src1_lo ? 1.f : 0.f; }
+    } else {
+      c.base = src0_img + (size_t)cbase * sizeof(T); c.cb = p.C0 * (int)sizeof(T);
+      if constexpr (LOIN) { c.lo = lo0_img + (size_t)cbase * sizeof(T); c.lw = p.src0_lo ? 1.f : 0.f; }
+    }
     return c;
   };
   auto load_piece = [&](int j, const ChunkSrc& cs) -> vec_t {  // raw 16 bytes of halo piece j
     return *(const vec_t*)(cs.base + (size_t)(__umul24(pix[j], cs.cb) + cpc * 16));
+  };
+  auto load_piece_lo = [&](int j, const ChunkSrc& cs) -> vec_t {  // the same piece of the lo plane (LO only)
+    return *(const vec_t*)(cs.lo + (size_t)(__umul24(pix[j], cs.cb) + cpc * 16));
   };
 
   // ---- GroupNorm coefficients of a chunk (BKE channels x (a,b) fp32): lanes 0..BKE/2-1 of wave 0 fetch 16 bytes =
@@ -194,10 +212,16 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     }
   };
   // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction)
-  auto xform_store = [&](int j, const vec_t& raw, char* sAdst) {
+  auto xform_store = [&](int j, const vec_t& raw, const vec_t& rawl, float lw, char* sAdst) {
     const char* cf = sAdst + 128 + cpc * (VE / 2) * AROW;
     float f[VE];
     vec_to_f32<T>(raw, f);
+    if constexpr (LOIN) {   // x = hi + lo (lw = 0 for a source without a lo plane)
+      float l[VE];
+      vec_to_f32<T>(rawl, l);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) f[e] = __builtin_fmaf(l[e], lw, f[e]);
+    }
 #pragma unroll
     for (int e = 0; e < VE; e += 2) {
       const f32x4 q = *(const f32x4*)(cf + (e / 2) * AROW);
@@ -260,8 +284,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     issue_b(0, 0, 0);
     const ChunkSrc cs0 = chunk_src(0);
     vec_t rawp[PIECES];
+    vec_t rawpl[LOIN ? PIECES : 1];
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) rawp[j] = load_piece(j, cs0);
+    if constexpr (LOIN) {
+#pragma unroll
+      for (int j = 0; j < PIECES; ++j) rawpl[j] = load_piece_lo(j, cs0);
+    }
     ab_store(q0, sA0);
     wait_vmcnt0();
     __syncthreads();  // coefficients of chunk 0 visible
@@ -276,6 +305,15 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
       float f[PIECES][VE];
 #pragma unroll
       for (int j = 0; j < PIECES; ++j) vec_to_f32<T>(rawp[j], f[j]);
+      if constexpr (LOIN) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+          float l[VE];
+          vec_to_f32<T>(rawpl[j], l);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) f[j][e] = __builtin_fmaf(l[e], cs0.lw, f[j][e]);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < VE / 2; ++k) {
         f32x2 v[PIECES], d[PIECES];
@@ -320,6 +358,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     char* sAn = sA0 + ((ch + 1) & 1) * A_BYTES;
     const ChunkSrc csn = chunk_src(MORE ? ch + 1 : ch);
     vec_t raw[2];
+    vec_t rawl[LOIN ? 2 : 1];
     f32x4 abq;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -332,16 +371,22 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
         // Counted waits: the raw halo piece of the latest issue window (always the newest VMEM operation of a wave,
         // issued AFTER the weights) may stay in flight -- it is consumed three steps later; everything older has landed.
         const bool prev_loaded = MORE && tap >= 1 && tap <= 6;
-        if (prev_loaded) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else wait_vmcnt0();
+        if (prev_loaded) {   // LO: the window's two newest operations are the hi and the lo piece
+          if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else wait_vmcnt0();
         __syncthreads();  // barrier X
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
         // issue window would make it wait for that window's weights)
-        vec_t cur;
+        vec_t cur, curl;
         if (do_store) cur = raw[tap & 1];
         asm volatile("" : "+v"(cur));  // pins the copy (and the compiler's vmcnt for it) here
+        if constexpr (LOIN) {
+          if (do_store) curl = rawl[tap & 1];
+          asm volatile("" : "+v"(curl));
+        }
         if (do_load && tap == 1) ab_store(abq, sAn);
         // issue window of the step (both groups in phase 1): the lagging group stages the whole weight slab of the NEXT
         // K-step (global time = the leading group's MFMA phase: the stage it overwrites was read until the last barrier),
@@ -350,6 +395,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
           raw[tap & 1] = load_piece(tap, csn);
+          if constexpr (LOIN) rawl[tap & 1] = load_piece_lo(tap, csn);
         }
         const char* const ap = aptr + (g * HW_ + t) * AROW;   // fragment mi adds mi halo rows of pixels
         if constexpr (IsSplit<T>::value) {
@@ -363,9 +409,9 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
           for (int mi = 0; mi < MI; ++mi) aH[mi] = lda(mi, 0);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) { bH[ni] = ldb(ni, 0); bL[ni] = ldb(ni, 16); }
-          if (do_store) xform_store(tap - 2, cur, sAn);
+          if (do_store) xform_store(tap - 2, cur, curl, csn.lw, sAn);
           // ---------- phase 2 ("mma") ----------
-          if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (bf16x3 has no LO instantiation)
           else wait_vmcnt0();
           __syncthreads();  // barrier Y
           __builtin_amdgcn_sched_barrier(0);
@@ -430,10 +476,12 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
         for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(ap + mi * HW_ * AROW);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * 4096);
-        if (do_store) xform_store(tap - 2, cur, sAn);
+        if (do_store) xform_store(tap - 2, cur, curl, csn.lw, sAn);
         // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
-        if (do_load) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else wait_vmcnt0();
+        if (do_load) {
+          if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else wait_vmcnt0();
         __syncthreads();  // barrier Y
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -752,13 +800,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
 // range walked side by side -- is bit-identical and 1.5-3 % slower on every layer (128^2 256->256: 1011 vs 1027 TF/s, 512->256:
 // 1199 vs 1218): the barrier between tiles and ~100 scalar spills of the hoisted launch constants cost more than the
 // workgroup dispatch it saves.)
-template <typename T, bool LO = false>
+template <typename T, bool LO = false, bool LOIN = false>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
-  fused_tile<T, LO>(p, xcd_remap(blockIdx.x, p.ntiles_total));
+  fused_tile<T, LO, LOIN>(p, xcd_remap(blockIdx.x, p.ntiles_total));
 }
 
-template <typename T, bool LO = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T, LO>;
+template <typename T, bool LO = false, bool LOIN = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T, LO, LOIN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -772,7 +820,8 @@ template <typename T, bool LO = false> int launch_fused(const FusedArgs& a, hipS
 }  // namespace
 
 // with optional lo planes of the output and the residual source (compensated 16-bit storage, precision mode fp16c)
-extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
+extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                                      int C1, const float* ab, int up,
                                       const void* weight, const float* bias, void* out, void* out_lo, const void* res,
                                       const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
                                       const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
@@ -802,11 +851,13 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const
         (size_t)H * W * smax * esz >= ((size_t)1 << 31) || (size_t)Cout * (skipC0 + skipC1) * esz >= ((size_t)1 << 32))
       return ivid_set_error("conv3x3_gn: image or weight matrix too large for 32-bit offsets", hipSuccess);
   }
-  if ((out_lo || res_lo) && esz != 2) return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype", hipSuccess);
+  const bool any_lo = out_lo || res_lo || src0_lo || src1_lo;
+  if (any_lo && esz != 2) return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype", hipSuccess);
+  if (src1_lo && C1 <= 0) return ivid_set_error("conv3x3_gn: src1_lo without src1", hipSuccess);
   if (res_lo && !res_mode) return ivid_set_error("conv3x3_gn: res_lo without a residual", hipSuccess);
   if (narrow)
     return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, skip0,
-                                skipC0, skip1, skipC1, skip_weight, stream, out_lo, res_lo);
+                                skipC0, skip1, skipC1, skip_weight, stream, out_lo, res_lo, src0_lo, src1_lo);
   FusedArgs a;
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.ab = ab; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page(); a.stats = stats;
@@ -815,11 +866,15 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, int C0, const
   a.tiles_x = W / TW; a.tiles_y = H / TH; a.ntiles_n = (Cout + BN - 1) / BN;
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
-  a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo;
+  a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo; a.src0_lo = (const char*)src0_lo; a.src1_lo = (const char*)src1_lo;
 #ifdef IVID_DEV_TIMELINE
   a.dbg = g_timeline;
 #endif
-  if (out_lo || res_lo) {
+  if (src0_lo || src1_lo) {
+    if (dtype == IVID_BF16) return launch_fused<__bf16, true, true>(a, (hipStream_t)stream);
+    return launch_fused<_Float16, true, true>(a, (hipStream_t)stream);
+  }
+  if (any_lo) {
     if (dtype == IVID_BF16) return launch_fused<__bf16, true>(a, (hipStream_t)stream);
     return launch_fused<_Float16, true>(a, (hipStream_t)stream);
   }
@@ -833,8 +888,8 @@ extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const v
                                     const void* weight, const float* bias, void* out, const void* res, int res_mode, int N,
                                     int H, int W, int Cout, float* stats, const void* skip0, int skipC0, const void* skip1,
                                     int skipC1, const void* skip_weight, void* stream) {
-  return ivid_conv3x3_gn_skip_c(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, nullptr, res, nullptr, res_mode, N, H, W,
-                                Cout, stats, skip0, skipC0, skip1, skipC1, skip_weight, stream);
+  return ivid_conv3x3_gn_skip_c(dtype, src0, nullptr, C0, src1, nullptr, C1, ab, up, weight, bias, out, nullptr, res, nullptr, res_mode,
+                                N, H, W, Cout, stats, skip0, skipC0, skip1, skipC1, skip_weight, stream);
 }
 
 #ifdef IVID_DEV_TIMELINE

@@ -17,4 +17,5 @@ bool ivid_fused128_supports(int dtype, int C0, int C1, int H, int W, int Cout, i
 int ivid_fused128_launch(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,
                          const void* weight, const float* bias, void* out, const void* res, int res_mode, int N, int H, int W,
                          int Cout, float* stats, const void* skip0, int skipC0, const void* skip1, int skipC1,
-                         const void* skip_weight, void* stream, void* out_lo = nullptr, const void* res_lo = nullptr);
+                         const void* skip_weight, void* stream, void* out_lo = nullptr, const void* res_lo = nullptr,
+                         const void* src0_lo = nullptr, const void* src1_lo = nullptr);

@@ -17,6 +17,8 @@ HIP launch plan (plan.py) on weights repacked once per precision:
     precision "fp16c" : the fp16 kernels with COMPENSATED storage: the residual trunk is stored as two fp16 planes hi + lo
                         (hi is the MFMA operand; residual adds, GroupNorm-apply and the head read hi + lo), stem and output
                         head are evaluated in split form -- <= 1e-3 from the fp32 reference at the fp16 MFMA rate
+    precision "fp16cx": fp16c + the lo planes also feed the fused kernels' GroupNorm / halo transform and the tensor between a
+                        ResBlock's two convolutions is compensated too (7.9e-4 instead of 8.7e-4 on the large model, 5 % slower)
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
 `use_fp16=True` configs select "fp16c" (the reference's fp16 torso, made to meet the fp32 tolerance); override with the
 extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
@@ -168,7 +170,7 @@ class AdmUnet2d(nn.Module):
                     "ivid_amd has no CPU execution path")
             _lib.load()
             dt = _lib.PRECISIONS[self.precision]
-            self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt, comp=self.precision in _lib.COMPENSATED)
+            self._packed = PackedWeights(self.spec, self.state_dict(), dev, dt, comp=_lib.COMPENSATED.get(self.precision, 0))
         return self._packed
 
     def plan(self, batch, stacked=False):

@@ -64,7 +64,7 @@ class PackedWeights:
 
     def __init__(self, spec: UNetSpec, sd, device, dtype, comp=False):
         self.dtype = dtype
-        self.comp = comp           # precision mode fp16c: compensated trunk storage, split stem and head
+        self.comp = int(comp)      # 1: precision mode fp16c (compensated trunk storage, split stem and head); 2: fp16cx (+ input lo planes)
         assert not comp or _lib.esz(dtype) == 2
         tdt = _TORCH_DT[dtype]
         self.kstep = 128 // _lib.esz(dtype)
@@ -201,6 +201,7 @@ class UNetPlan:
         self.taps = {}
         self.dtype = weights.dtype
         self.comp = weights.comp
+        self.comp_in = weights.comp >= 2     # fp16cx: lo planes feed the fused halo transform; h1 is compensated too
         self.esz = _lib.esz(self.dtype)
         self.bsrc = bsrc
         self.n = 2 * bsrc if stacked else bsrc
@@ -343,10 +344,12 @@ class UNetPlan:
     def _conv3_gn(self, x0: _Act, x1, ab, up, wname, out: _Act, res_ptr, res_mode, skip=None, res_lo=None):
         """Fused GroupNorm-apply + SiLU (+ x2 upsample) + conv3x3 (csrc/conv3x3_fused.hip).  skip = (s0, s1, wname): the
         ResBlock's 1x1 skip_connection on its raw input cat(s0, s1), accumulated in the same kernel.  The halo transform and
-        the skip phase read the hi planes of their sources (MFMA operands); out / res may carry lo planes."""
+        the skip phase's raw inputs are MFMA operands (hi planes); the halo transform starts from hi + lo where a source has a
+        lo plane; out / res may carry lo planes."""
         out.stats_blk = 128
         st = out.stats.data_ptr() if out.stats is not None else None
-        if out.lo is not None or res_lo is not None:
+        lo0, lo1 = (x0.lo_ptr, (x1.lo_ptr if x1 is not None else None)) if self.comp_in else (None, None)
+        if out.lo is not None or res_lo is not None or lo0 is not None or lo1 is not None:
             bias = self.w[wname + ".bias"]
             s0 = s1 = sname = None
             if skip is not None:
@@ -355,7 +358,7 @@ class UNetPlan:
                 if key not in self._sum_bias:
                     self._sum_bias[key] = (self.w[wname + ".bias"] + self.w[sname + ".bias"]).contiguous()
                 bias = self._sum_bias[key]
-            self._rec("ivid_conv3x3_gn_skip_c", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
+            self._rec("ivid_conv3x3_gn_skip_c", self.dtype, x0.ptr, lo0, x0.c, x1.ptr if x1 is not None else None, lo1,
                       x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
                       bias.data_ptr(), out.ptr, out.lo_ptr, res_ptr, res_lo, res_mode, out.n, out.side, out.side, out.c, st,
                       s0.ptr if s0 is not None else None, s0.c if s0 is not None else 0,
@@ -387,7 +390,10 @@ class UNetPlan:
         narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and so % 32 == 0
         fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
-        h1 = self._new(n, so, op.cout, stats=True)
+        up4 = (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0 and op.cout > 32)
+        # fp16cx: h1 (between the block's two convolutions) carries a lo plane too: out_layers' GroupNorm then
+        # sees the unrounded in_layers result (not behind the phase-form up-convolution, whose epilogue scatters single planes)
+        h1 = self._new(n, so, op.cout, stats=True, trunk=self.comp_in and not up4)
         if (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0
                 and op.cout > 32):
             # activated tensor at the SOURCE size (a quarter of the bytes of the upsampled one), then the phase convolution
@@ -405,15 +411,17 @@ class UNetPlan:
             # runs on the first half; its output and its GroupNorm partials are duplicated (image-major layouts: a half is
             # one contiguous block).
             half = self.bsrc
-            xh = _Act(x.buf, half, x.side, x.c, x.stats)
+            xh = _Act(x.buf, half, x.side, x.c, x.stats, lo=x.lo)
             xh.stats_blk = x.stats_blk
-            h1h = _Act(h1.buf, half, so, op.cout, h1.stats)
+            h1h = _Act(h1.buf, half, so, op.cout, h1.stats, lo=h1.lo)
             ab1 = self._gn_coeffs(xh, None, op.prefix + ".in_layers.0", None)
             self._conv3_gn(xh, None, ab1, False, op.prefix + ".in_layers.2", h1h, None, 0)
             h1.stats_blk = h1h.stats_blk
             self.arena.put(ab1)
             nb = half * so * so * op.cout * self.esz
             self._rec("ivid_copy", h1.ptr + nb, h1.ptr, nb)
+            if h1.lo is not None:
+                self._rec("ivid_copy", h1.lo_ptr + nb, h1.lo_ptr, nb)
             if h1.stats is not None:
                 sb = half * (so * so // h1.stats_blk) * op.cout * 2 * 4
                 self._rec("ivid_copy", h1.stats.data_ptr() + sb, h1.stats.data_ptr(), sb)
@@ -424,7 +432,7 @@ class UNetPlan:
         else:
             act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
             self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
-                       op.cout, 9, out_act=h1)
+                       op.cout, 9, out_act=h1, out_lo=h1.lo_ptr)
             self._free(act1)
         if fused2:
             ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off)
@@ -470,9 +478,9 @@ class UNetPlan:
 
     def _attn(self, op: Attn, x: _Act):
         n, side, c = x.n, x.side, x.c
-        # the attention branch reads the hi plane alone: its input rounding is damped by the softmax average and proj_out
-        # (error budget 8.674e-4 with vs 8.679e-4 without the lo plane, tests/tools/error_budget.py kind N) -- half the bytes
-        xn = self._gn(x, None, op.prefix + ".norm", None, 0, 0, use_lo=False)
+        # (reading the hi plane alone here saves 0.4 ms per large forward and costs nothing on the large model, but it takes
+        # small-128 from 9.2e-4 to 9.7e-4 of the reference: the lo plane stays)
+        xn = self._gn(x, None, op.prefix + ".norm", None, 0, 0)
         qkv = self._new(n, side, 3 * c)
         self._conv(self.dtype, xn.ptr, c, None, 0, op.prefix + ".qkv", qkv.ptr, None, 0, 0, n, side, side, 3 * c, 1)
         self._free(xn)

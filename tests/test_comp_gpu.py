@@ -143,9 +143,12 @@ FUSED_C = [
 ]
 
 
+@pytest.mark.parametrize("in_lo", [False, True], ids=["in_hi", "in_hi+lo"])
 @pytest.mark.parametrize("dtype", DT16)
 @pytest.mark.parametrize("case", FUSED_C, ids=[c[0] for c in FUSED_C])
-def test_conv3x3_gn_skip_c_lo_planes(case, dtype):
+def test_conv3x3_gn_skip_c_lo_planes(case, dtype, in_lo):
+    """in_lo: the first convolution input carries a lo plane (the halo transform starts from hi + lo); a concat partner stays a
+    plain tensor, which exercises the weight-0 stand-in of a source without a lo plane."""
     name, N, H, W, C0, C1, Cout, res_mode, (S0, S1) = case
     L = G.lib()
     s = sum(map(ord, name)) % 1000
@@ -157,7 +160,12 @@ def test_conv3x3_gn_skip_c_lo_planes(case, dtype):
     w = common.seeded_randn(s + 3, Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
     bias = common.seeded_randn(s + 4, Cout) * 0.1
     res = res_for(res_mode, s + 5, N, Cout, H, W)
-    x = G.rounded(x0 if x1 is None else torch.cat([x0, x1], 1), dtype)
+    x0 = x0 * 3.0                                    # spread the values over several binades: the lo plane matters
+    if in_lo:
+        d0, d0l, x0v = planes(x0, dtype)
+    else:
+        d0, d0l, x0v = G.to_nhwc(x0, dtype), None, G.rounded(x0, dtype)
+    x = x0v if x1 is None else torch.cat([x0v, G.rounded(x1, dtype)], 1)
     act = G.rounded(F.silu(x * a[:, :, None, None] + b[:, :, None, None]), dtype)
     ref = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1)
     sk0 = sk1 = wsk = None
@@ -175,18 +183,18 @@ def test_conv3x3_gn_skip_c_lo_planes(case, dtype):
     out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=G.tdt(dtype))
     out_lo = torch.full_like(out, float("nan"))
     stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
-    d0, d1 = G.to_nhwc(x0, dtype), (G.to_nhwc(x1, dtype) if x1 is not None else None)
+    d1 = G.to_nhwc(x1, dtype) if x1 is not None else None
     ab = torch.stack([a, b], -1).contiguous().cuda()
     wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
     bd = bias.cuda()
-    L.call("ivid_conv3x3_gn_skip_c", dtype, L.ptr(d0), C0, L.ptr(d1), C1, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out),
+    L.call("ivid_conv3x3_gn_skip_c", dtype, L.ptr(d0), L.ptr(d0l), C0, L.ptr(d1), None, C1, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out),
            L.ptr(out_lo), L.ptr(rh), L.ptr(rl), res_mode, N, H, W, Cout, L.ptr(stats), L.ptr(sk0), S0, L.ptr(sk1), S1, L.ptr(wsk),
            G.stream())
     torch.cuda.synchronize()
     got = joined(out, out_lo)
     e = common.rel_l2(got, ref.float())
     e_hi = common.rel_l2(G.from_nhwc(out), ref.float())
-    G.report(f"conv3x3_gn_c/{name}/{G.DN[dtype]}", rel_l2=e, rel_l2_hi_plane_alone=e_hi)
+    G.report(f"conv3x3_gn_c/{name}/{G.DN[dtype]}/{'in_lo' if in_lo else 'in_hi'}", rel_l2=e, rel_l2_hi_plane_alone=e_hi)
     assert torch.isfinite(got).all()
     # the halo transform's hardware exp / rcp move a few activations across a 16-bit rounding boundary (~1e-5 on the output)
     assert e < (2e-4 if dtype == 1 else 6e-5), f"{name}: hi + lo is {e} from the fp32 result"

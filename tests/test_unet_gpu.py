@@ -17,7 +17,7 @@ from oracle import adm_oracle, sampler_oracle
 pytestmark = pytest.mark.gpu
 PARITY_BAR = 1e-3
 # precision -> bar on one forward's rel-L2 vs the reference fp32 output
-MODE_BAR = {"bf16": 1.2e-2, "fp16": 1.5e-3, "fp16c": PARITY_BAR, "bf16x3": PARITY_BAR}
+MODE_BAR = {"bf16": 1.2e-2, "fp16": 1.5e-3, "fp16c": PARITY_BAR, "fp16cx": PARITY_BAR, "bf16x3": PARITY_BAR}
 
 
 def build(args, seed, precision):
@@ -112,7 +112,7 @@ def test_stacked_cfg_forward_shares_the_class_independent_prefix_bit_exactly(pre
         assert ncopy[0] == 2 and ncopy[1] == 0, ncopy
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "fp16cx", "bf16x3"])
 @pytest.mark.parametrize("name,args,seed", [("mini_fwd", C.MINI, 0), ("mini_cond_fwd", C.MINI_COND, 2)])
 def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
     m, sd = build(args, seed, precision)
@@ -275,7 +275,7 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
     assert abs(float(x_T.double().sum()) - float(g["x_checksum"])) < 1e-6
     cls = torch.from_numpy(g["classes"]).cuda()
     errs = {}
-    for prec in ("fp32", "bf16x3", "fp16c", "fp16", "bf16"):
+    for prec in ("fp32", "bf16x3", "fp16cx", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
         torch.manual_seed(3)
         res = smp.sample(2, noise=x_T.cuda(), classes=cls, steps=int(g["steps"]), strength=float(g["strength"]), verbose=False,
@@ -287,7 +287,7 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
         assert torch.isfinite(res.samples).all()
     print("config 2 chain, samples rel-L2 vs the reference:", {k: v["samples"] for k, v in errs.items()})
     assert errs["fp32"]["samples"] < 1e-4
-    for prec in ("bf16x3", "fp16c"):
+    for prec in ("bf16x3", "fp16cx", "fp16c"):
         assert errs[prec]["samples"] < PARITY_BAR, (prec, errs[prec])
     assert errs["fp16"]["samples"] < 10 * MODE_BAR["fp16"] and errs["bf16"]["samples"] < 10 * MODE_BAR["bf16"]
 
@@ -305,9 +305,15 @@ def test_fp16c_keeps_the_trunk_as_hi_plus_lo_planes():
     m2, _ = build(C.MINI, 0, "fp16")
     m2(x.cuda(), t.cuda(), cls.cuda())
     assert not [n for _, n, _ in m2.plan(2, False).launches if n.endswith("_c") or n.endswith("_split")]
+    # fp16cx: the fused launches are handed the lo planes of their inputs as well (arguments 2 / 5 of ivid_conv3x3_gn_skip_c)
+    fused = lambda mm: [a for _, n, a in mm.plan(2, False).launches if n == "ivid_conv3x3_gn_skip_c"]
+    assert all(a[2] is None and a[5] is None for a in fused(m))
+    m3, _ = build(C.MINI, 0, "fp16cx")
+    m3(x.cuda(), t.cuda(), cls.cuda())
+    assert fused(m3) and sum(1 for a in fused(m3) if a[2] is not None) >= len(fused(m3)) - 2
 
 
-@pytest.mark.parametrize("precision", ["fp16c", "fp16"])
+@pytest.mark.parametrize("precision", ["fp16c", "fp16cx", "fp16"])
 def test_16bit_forward_is_bitwise_batch_invariant(precision):
     """The sharding invariant in the headline precision: a sample's output must not depend on the batch it is computed in (ranks
     get different batch sizes: ragged last batches, `seeds[rank::world]`).  Statistics blocks, summation orders and the hi / lo
