@@ -292,6 +292,30 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
     assert errs["fp16"]["samples"] < 10 * MODE_BAR["fp16"] and errs["bf16"]["samples"] < 10 * MODE_BAR["bf16"]
 
 
+def test_forward_deviation_on_a_structured_input_large128():
+    """The committed reference output (large128_fwd.npz) is for a pure-noise input at t = 999.  The relative deviation of a 16-bit
+    forward depends on the input: on a smooth / mixed input the network's output is smaller against the same operand roundings
+    (tests/tools/error_budget.py: fp16c 1.07e-3, fp16cx 0.95e-3, fp16 1.3e-3 emulated).  Measured here against the oracle on the
+    host (pinned to the reference bit-for-bit), reported, and held to bars that say what each mode delivers PER FORWARD on such
+    inputs; the sampler's OUTPUT (the config-2 chain test above) is what BASELINE.json's 1e-3 is claimed on."""
+    m, sd = build(C.LARGE128, 4, "bf16x3")
+    n = C.seeded_randn(104, 1, 4, 128, 128)
+    sm = torch.nn.functional.interpolate(C.seeded_randn(105, 1, 4, 8, 8), size=128, mode="bilinear")
+    x = 0.5 * n + 0.5 * sm
+    t = torch.full((1,), 500, dtype=torch.long)
+    cls = torch.tensor([7])
+    ref = adm_oracle.unet_forward(sd, C.LARGE128, x, t, cls)
+    errs = {}
+    for prec in ("bf16x3", "fp16cx", "fp16c", "fp16", "bf16"):
+        m.set_precision(prec)
+        errs[prec] = C.rel_l2(m(x.cuda(), t.cuda(), cls.cuda()).cpu(), ref)
+    G.report("unet/large128_structured_input_t500", **errs)
+    print("structured input, t = 500:", errs)
+    assert errs["bf16x3"] < 1e-4
+    assert errs["fp16cx"] < 1.05e-3 and errs["fp16c"] < 1.2e-3 and errs["fp16cx"] < errs["fp16c"] < errs["fp16"] < 1.6e-3
+    assert errs["bf16"] < MODE_BAR["bf16"]
+
+
 def test_fp16c_keeps_the_trunk_as_hi_plus_lo_planes():
     """Precision mode fp16c: the launch plan routes every tensor of the residual stream through the `_c` entry points (lo
     planes written and read), the stem through ivid_stem_im2col_split and the head through the split form; plain fp16 uses none."""
