@@ -162,7 +162,7 @@ def main(argv=None):
     p.add_argument("--atol", type=float, default=0.03)
     p.add_argument("--rtol", type=float, default=0.03)
     p.add_argument("--erode_rgb", type=int, default=3)
-    p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 | fp16c (fp16 MFMA, compensated trunk: within 1e-3 of fp32) | fp16 | bf16; default: fp16c if the config says use_fp16 else fp32")
+    p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 | fp16cx | fp16c (fp16 MFMA, compensated trunk: within 1e-3 of fp32) | fp16 | bf16; default: fp16c if the config says use_fp16 else fp32")
     # 128 -> 256 super-resolution of every generated view (BASELINE config 5).  Not in the reference CLI: the reference ships
     # the SR model and SuperResCFG but no inference driver for them (only SuperResTrainer.sample, trainers/superres.py:97-134)
     p.add_argument("--config_sr", type=str, default=None, help="e.g. configs/rgbd_imagenet_adm_256_128_small_sr.json")
