@@ -51,6 +51,16 @@ DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx"
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
+# `dtype` of the bench line = the arithmetic type of the MFMA operands; `precision_mode` = the mode of this package
+ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "bf16x3": "bf16"}
+MODE_NOTE = {
+    "fp32": "fp32 storage, exact fp32 MFMA",
+    "bf16": "bf16 storage and MFMA operands, fp32 accumulate",
+    "fp16": "fp16 storage and MFMA operands, fp32 accumulate (the reference's use_fp16 torso)",
+    "fp16c": "fp16 MFMA operands, fp32 accumulate; residual trunk stored as two fp16 planes hi + lo; stem and head in split form",
+    "fp16cx": "fp16c + lo planes also feed the fused kernels' GroupNorm, h1 compensated too",
+    "bf16x3": "fp32 storage; operands split into bf16 hi + lo, 3 bf16 MFMAs per product",
+}
 PARITY_TOL = 1e-3                                           # BASELINE.json north_star: outputs within 1e-3 of the reference
 SPEED_ORDER = ["bf16", "fp16", "fp16c", "fp16cx", "bf16x3"]  # fastest first (measured: profiles/r03_*)
 
@@ -431,7 +441,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.precision, "data": "synthetic (seeded random-init weights, N(0,1) x_T)",
+        "dtype": ARITH[a.precision], "precision_mode": a.precision, "precision_mode_note": MODE_NOTE[a.precision],
+        "data": "synthetic (seeded random-init weights, N(0,1) x_T)",
         "config": {"workload": "%s, DDIM 50-step schedule, bs=%d per GPU, CFG=%.2f "
                                "(1 step = %d UNet forwards stacked into one batch-%d hipGraph forward + fused DDIM update)"
                                % (res_name, B, a.guidance if has_cls else 0.0, fwd_per_step, B * fwd_per_step),
@@ -519,7 +530,7 @@ def main():
         pdt = timed(psteps, 2)
         pf = fwd_per_step * psteps * world / pdt
         ptf = pf * B * gflop / 1e3
-        modes[pp] = {"dtype": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
+        modes[pp] = {"dtype": ARITH[pp], "precision_mode": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
                      "ms_per_step": round(1e3 * pdt / psteps, 3), "job_tflops": round(ptf, 2),
                      "frac": round(ptf / world / PEAK_TFLOPS[pp], 4)}
     model.set_precision(a.precision)
@@ -542,7 +553,7 @@ def main():
         result["parity_mode"] = dict(modes.pop(a.parity_precision),
                                      frac_note="algorithmic FLOPs / dense bf16 MFMA peak (the 3 MFMAs per product are overhead)")
     elif a.precision == a.parity_precision or dev_tab.get(a.precision, 1.0) <= PARITY_TOL:
-        result["parity_mode"] = {"dtype": a.precision, "note": "the headline mode itself is inside the tolerance"}
+        result["parity_mode"] = {"dtype": ARITH[a.precision], "precision_mode": a.precision, "note": "the headline mode itself is inside the tolerance"}
     if modes:
         result["other_modes"] = list(modes.values())
 
@@ -662,7 +673,8 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
         "metric": "samples/s end to end, BASELINE " + label,
         "value": round(bs * world / dt, 4), "unit": "samples/s (%d views each: 1 unconditional + %d warped/inpainted)" % (nviews, nviews - 1),
         "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded random-init weights)",
+        "scaling": "weak", "vs_baseline": None, "dtype": ARITH[a.precision], "precision_mode": a.precision,
+        "data": "synthetic (seeded random-init weights)",
         "config": {"workload": "rgbd_imagenet_adm_128_large_cfg (DDPM %d steps, CFG 3.0) + rgbd_imagenet_adm_128_large_cond "
                                "(DDIM %d steps, InpaintCFG 3.0), viewset %s, bs=%d per GPU, HIP depth-warp in the loop%s"
                                % (su, sc, "random" if a.config == "c3" else "3x9", bs,

@@ -11,7 +11,7 @@ IVID_BENCH_LAYERS=gpurun_out/layers_fp16c.json timeout 900 python bench.py > gpu
 echo "bench exit $?"; python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/bench_default.json").read().strip().splitlines()[-1])
-print(d["dtype"], d["value"], d["ms_per_step"], d["mfma_roofline_frac_whole_step"], d.get("rel_l2_vs_reference"))
+print(d["precision_mode"], d["dtype"], d["value"], d["ms_per_step"], d["mfma_roofline_frac_whole_step"], d.get("rel_l2_vs_reference"))
 print(d["kernel_time_ms_per_forward"])
 PY
 tail -3 gpurun_out/bench_default.err
