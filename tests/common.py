@@ -70,3 +70,31 @@ def max_rel(a, b):
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+# ---- the representative forward set (round 4): inputs a sampling chain actually feeds the network ----
+FWD_SET_T = (0, 20, 250, 500, 750, 999)
+# (tag, synthetic_rgbd kwargs, class): one band-limited scene and one layered scene with white-noise colours
+FWD_SET_SCENES = (("smooth", dict(seed=0, smooth_color=True, layers=False), 7),
+                  ("layers", dict(seed=1, smooth_color=False, layers=True), 416))
+
+
+def fwd_set_inputs(in_channels=4, S=128):
+    """[(key, x_t [1,C,S,S] fp32, t, class)] with x_t = sqrt(abar_t) * x0 + sqrt(1 - abar_t) * n (gaussian_diffusion.py:45-56,
+    linear betas, 1000 timesteps), x0 = tests/warp_common.synthetic_rgbd in [-1, 1], n = seeded_randn(7000 + 100*scene + index of t).
+    The same recipe runs in tests/golden/make_golden_fwd_set.py (live reference) and on the GPU box."""
+    import warp_common as WC
+    betas = np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)
+    abar = np.cumprod(1.0 - betas)
+    out = []
+    for si, (tag, kw, cls) in enumerate(FWD_SET_SCENES):
+        x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
+        if in_channels > 4:   # conditional / SR models: the remaining channels carry the clean scene (y, mask-like planes)
+            x0 = torch.cat([x0, x0[:, : in_channels - 4]], 1)
+        for ti, t in enumerate(FWD_SET_T):
+            n = seeded_randn(7000 + 100 * si + ti, 1, in_channels, S, S)
+            x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
+            if in_channels > 4:
+                x[:, 4:] = x0[:, 4:]
+            out.append((f"{tag}_t{t}", x.contiguous(), t, cls))
+    return out

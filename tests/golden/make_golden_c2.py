@@ -5,6 +5,10 @@ deterministic synthetic checkpoint, ClassifierFreeGuidance (classifier_free_guid
 (samplers/ddim.py:105-165): 50 steps, strength 0.5, eta 0, batch 2, recorded x_T.  ~200 CPU forwards of the large model.
 Writes tests/golden/large128_ddim50_cfg.npz (samples, first / middle / last pred_x_0) and checks the oracle chain
 against the reference's samples while it is at it (the oracle pin of this chain).
+Round 4: also records, TEACHER-FORCED, what the reference's framework saw and answered at steps 1, 10, 25 and 49 of that chain
+(model_inference's input x_t, timestep and guided eps, classifier_free_guidance.py:39-42) -> large128_ddim50_cfg_steps.npz, so
+that a product forward can be compared on the chain's own inputs step by step (the samples alone cannot see steps 2-50: the
+synthetic-weight chain is dominated by its first x0 estimate).
 """
 import json
 import os
@@ -49,6 +53,7 @@ from oracle import adm_oracle, sampler_oracle  # noqa: E402
 
 torch.set_num_threads(os.cpu_count())
 STEPS, STRENGTH, B = 50, 0.5, 2
+REC_STEPS = (1, 10, 25, 49)   # 0-based index of the sample_once call
 
 
 @torch.no_grad()
@@ -63,9 +68,25 @@ def main():
     cls = torch.tensor([7, 416])
     torch.manual_seed(3)
     t0 = time.time()
+    rec, calls, inner = {}, [0], fw.model_inference
+
+    def spy(x_t, t, classes=None, **kw):
+        out = inner(x_t, t, classes=classes, **kw)
+        if calls[0] in REC_STEPS:
+            k = calls[0]
+            rec[f"x_step{k}"], rec[f"eps_step{k}"], rec[f"t_step{k}"] = x_t.numpy().copy(), out.numpy().copy(), np.int64(int(t[0]))
+        calls[0] += 1
+        return out
+    fw.model_inference = spy
     ref = smp.sample(B, noise=x_T, classes=cls, steps=STEPS, strength=STRENGTH, verbose=False)
     dt = time.time() - t0
+    fw.model_inference = inner
     print(f"reference chain: {dt:.1f} s", flush=True)
+    old = os.path.join(HERE, "large128_ddim50_cfg.npz")
+    if os.path.exists(old):   # the spy must not have changed the chain
+        assert np.array_equal(np.load(old)["samples"], ref.samples.numpy()), "chain differs from the committed golden"
+    rec["classes"] = cls.numpy()
+    np.savez_compressed(os.path.join(HERE, "large128_ddim50_cfg_steps.npz"), **rec)
     arrays = dict(samples=ref.samples.numpy(), x0_first=ref.pred_x_0[0].numpy(), x0_mid=ref.pred_x_0[STEPS // 2].numpy(),
                   x0_last=ref.pred_x_0[-1].numpy(), classes=cls.numpy(), x_checksum=np.float64(x_T.double().sum()),
                   steps=np.int64(STEPS), strength=np.float64(STRENGTH))
