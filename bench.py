@@ -44,21 +44,23 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
 # flops (its 3 MFMAs per product are overhead, not work)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "fp16s": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
-DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2}
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2}
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
 # `dtype` of the bench line = the arithmetic type of the MFMA operands; `precision_mode` = the mode of this package
-ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "bf16x3": "bf16"}
+ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "fp16s": "fp16", "bf16x3": "bf16"}
 MODE_NOTE = {
     "fp32": "fp32 storage, exact fp32 MFMA",
     "bf16": "bf16 storage and MFMA operands, fp32 accumulate",
     "fp16": "fp16 storage and MFMA operands, fp32 accumulate (the reference's use_fp16 torso)",
     "fp16c": "fp16 MFMA operands, fp32 accumulate; residual trunk stored as two fp16 planes hi + lo; stem and head in split form",
     "fp16cx": "fp16c + lo planes also feed the fused kernels' GroupNorm, h1 compensated too",
+    "fp16s": "fp16cx + every 1x1 skip_connection in split precision (3 MFMA passes) + stem and first encoder level as a "
+             "split-precision island (fp32 storage, bf16 hi + lo operands, 3 MFMA passes)",
     "bf16x3": "fp32 storage; operands split into bf16 hi + lo, 3 bf16 MFMAs per product",
 }
 PARITY_TOL = 1e-3                                           # BASELINE.json north_star: outputs within 1e-3 of the reference
@@ -219,6 +221,10 @@ def canonical_launch(name, args):
         plane = n * h * w * cout * ESZ[dt]
         extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
         return "ivid_conv2d", tuple(a for i, a in enumerate(args) if i not in (8, 10)), float(extra)
+    if name == "ivid_conv3x3_gn_skip_s":   # the split skip phase re-reads the skip sources' lo planes and the lo weights
+        sk_lo = args[16] * args[17] * args[18] * (args[22] + args[24]) * ESZ[args[0]]
+        nm, a2, extra = canonical_launch("ivid_conv3x3_gn_skip_c", args[:26])
+        return nm, a2, extra + float(sk_lo)
     if name == "ivid_conv3x3_gn_skip_c":
         (dt, _s0, s0lo, c0, _s1, s1lo, c1, _ab, up, _w, _b, _o, olo, _r, rlo, rm, n, h, w, cout) = args[:20]
         plane = n * h * w * cout * ESZ[dt]
@@ -247,7 +253,9 @@ def kernel_table(prof, precision):
         f["byt"] += lo_bytes
         if name == "ivid_conv2d":
             fl, _ = conv_flops(args)
-            f["flop"] += fl
+            # a launch without bias is a correction pass of a split-precision 1x1 skip convolution (fp16s: + x_lo.w_hi,
+            # + x_hi.w_lo): executed work, not algorithmic work
+            f["flop"] += fl if args[6] else 0.0
             f["byt"] += conv_bytes(args, False)
         elif name == "ivid_conv3x3_up":
             f["flop"] += up_flops(args)

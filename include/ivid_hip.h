@@ -69,6 +69,8 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_GN_APPLY_C 17     /* ivid_gn_apply_c */
 #define IVID_OP_CONV3X3_GN_OUT_C 18 /* ivid_conv3x3_gn_out_c */
 #define IVID_OP_STEM_IM2COL_SPLIT 19 /* ivid_stem_im2col_split */
+#define IVID_OP_CONV3X3_GN_SKIP_S 20 /* ivid_conv3x3_gn_skip_s */
+#define IVID_OP_F32_TO_HILO 21    /* ivid_f32_to_hilo */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -170,6 +172,18 @@ int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* src0_lo, int
                            const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0,
                            int skipC0, const void* skip1, int skipC1, const void* skip_weight, void* stream);
 
+/* ivid_conv3x3_gn_skip_c with the 1x1 skip phase in SPLIT precision (precision mode fp16s).  `self.skip_connection(x) + h`
+ * (adm.py:190,222) sends the residual trunk itself through an MFMA: every operand rounding of that 1x1 convolution reaches
+ * all later layers undamped (measured: 40 % of the fp16cx deviation on clean inputs).  With skip_weight_lo != NULL the phase
+ * accumulates x_hi.w_hi + x_lo.w_hi + x_hi.w_lo (x_lo: the lo planes skip0_lo / skip1_lo of the block input, one per source;
+ * w_lo = fp16(w - fp16(w)) in the layout of skip_weight): three MFMA passes over the 1x1 K range, four staged slabs per
+ * chunk.  IVID_F16 and Cout > 128 only.  skip_weight_lo == NULL: identical to ivid_conv3x3_gn_skip_c. */
+int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1,
+                           const float* ab, int up, const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                           const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0,
+                           int skipC0, const void* skip1, int skipC1, const void* skip_weight, const void* skip0_lo,
+                           const void* skip1_lo, const void* skip_weight_lo, void* stream);
+
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].
  *   src NHWC [N,H,W,C] in `dtype`; ab fp32 [N][C][2]; weight [Cout][9][C] in `dtype`; 1 <= Cout <= 16; W % 32 == 0, H % 8 == 0.
@@ -235,6 +249,11 @@ int ivid_silu_f32(const float* x, float* y, long long n, void* stream);
  * common: until the first FiLM (adm.py:214-218) nothing depends on the class, so the first ResBlock's in_layers convolution
  * is computed for one half and duplicated with this call. */
 int ivid_copy(void* dst, const void* src, long long bytes, void* stream);
+
+/* fp32 tensor of n elements (n % 8 == 0) -> two planes in the 16-bit `dtype`: hi = T(x), lo = T(x - hi): hands a tensor of
+ * the split-precision island of the fp16s mode (fp32 storage: the stem and the first encoder level, adm.py:373-402) to the
+ * 16-bit part of the network in its compensated storage form. */
+int ivid_f32_to_hilo(int dtype, const float* src, void* hi, void* lo, long long n, void* stream);
 
 /* ---- model boundary layout changes ----
  * fp32 NCHW [Bsrc,Cin,H,W] -> NHWC dtype [N,H,W,Cpad] (zero padded channels, batch replicated n % Bsrc). */

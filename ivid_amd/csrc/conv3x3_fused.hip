@@ -61,6 +61,11 @@ struct FusedArgs {
   const char* res_lo;
   const char* src0_lo;
   const char* src1_lo;
+  // split-precision skip phase (SKS instantiation, precision mode fp16s): lo planes of the skip sources and the lo part of
+  // the skip weights; the phase then accumulates x_hi.w_hi + x_lo.w_hi + x_hi.w_lo
+  const char* sk0_lo;
+  const char* sk1_lo;
+  const char* skw_lo;
 #ifdef IVID_DEV_TIMELINE
   unsigned long long* dbg;             // [blocks][8] phase time stamps (scripts/dev/fused_timeline.py)
 #endif
@@ -92,7 +97,8 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // One output tile (8 x 32 pixels x 256 output channels) of the launch: the whole kernel body.  `tile` is the logical tile id.
 // LO: output / residual lo planes in the epilogue.  LOIN: the halo transform reads lo planes of the inputs as well.
-template <typename T, bool LO, bool LOIN>
+// SKS: the 1x1 skip phase runs in split precision (three MFMA passes per chunk).
+template <typename T, bool LO, bool LOIN, bool SKS>
 __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -558,26 +564,41 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
       const int wrow = min(n0 + row, p.Cout - 1);
       sb_voff[i] = (unsigned)((size_t)wrow * sk_ctot * sizeof(T)) + swz;
     }
-    auto issue_skip = [&](int stage, int c) {
+    // One virtual step v of the phase.  Plain: v = chunk c, both operands of the chunk go to stage v&1.  SKS (the trunk itself
+    // passes through this 1x1 convolution -- adm.py:190,222 -- so its operand roundings reach every later layer undamped): three
+    // steps per chunk, s = 0: x_hi.w_hi, s = 1: x_lo.w_hi, s = 2: x_hi.w_lo.  The A and B stages are managed separately so that
+    // only FOUR slabs are staged per chunk: step 1 keeps the w_hi slab of step 0, step 2 finds x_hi still in step 0's A stage
+    // (step 1 staged x_lo into the other one).  A stage of (c, s) = (c + (s == 1)) & 1, B stage = (s == 2).
+    const int nv = SKS ? 3 * sk_chunks : sk_chunks;
+    auto stage_a = [&](int v) -> int { return SKS ? ((v / 3 + ((v % 3) == 1 ? 1 : 0)) & 1) : (v & 1); };
+    auto stage_b = [&](int v) -> int { return SKS ? ((v % 3) == 2 ? 1 : 0) : (v & 1); };
+    auto issue_skip = [&](int v) {
+      const int c = SKS ? v / 3 : v, sub = SKS ? v % 3 : 0;
       const int cbase = c * BKE;
       const bool second = cbase >= p.skC0;
-      const char* abase = second ? sk1_img + (size_t)(cbase - p.skC0) * sizeof(T) : sk0_img + (size_t)cbase * sizeof(T);
-      const int cb = (second ? p.skC1 : p.skC0) * (int)sizeof(T);
-      const char* wbase = p.skw + (size_t)cbase * sizeof(T);
+      if (!SKS || sub != 2) {
+        const char* b0 = (SKS && sub == 1) ? p.sk0_lo + sk_px * p.skC0 * sizeof(T) : sk0_img;
+        const char* b1 = (SKS && sub == 1) ? p.sk1_lo + sk_px * p.skC1 * sizeof(T) : sk1_img;
+        const char* abase = second ? b1 + (size_t)(cbase - p.skC0) * sizeof(T) : b0 + (size_t)cbase * sizeof(T);
+        const int cb = (second ? p.skC1 : p.skC0) * (int)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        glds16_s(abase, __umul24(spix[i], cb) + swz, sA0 + stage * 32768 + (i * NT + wave * 64) * 16);
+        for (int i = 0; i < 4; ++i)
+          glds16_s(abase, __umul24(spix[i], cb) + swz, sA0 + stage_a(v) * 32768 + (i * NT + wave * 64) * 16);
+      }
+      if (!SKS || sub != 1) {
+        const char* wbase = ((SKS && sub == 2) ? p.skw_lo : p.skw) + (size_t)cbase * sizeof(T);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16_s(wbase, sb_voff[i], sB0 + stage * B_BYTES + (i * NT + wave * 64) * 16);
+        for (int i = 0; i < 4; ++i) glds16_s(wbase, sb_voff[i], sB0 + stage_b(v) * B_BYTES + (i * NT + wave * 64) * 16);
+      }
     };
     const int sa_addr0 = (wm * 128 + frow) * 128 + (((FH * fhalf) ^ (((wm * 128 + frow) >> 1) & 7)) << 4);
-    issue_skip(0, 0);
-    for (int c = 0; c < sk_chunks; ++c) {
+    issue_skip(0);
+    for (int c = 0; c < nv; ++c) {
       wait_vmcnt0();
-      __syncthreads();  // stage c&1 landed for every wave; everyone finished reading the other stage
-      if (c + 1 < sk_chunks) issue_skip((c + 1) & 1, c + 1);
-      const int a_off = (c & 1) * 32768 + sa_addr0;
-      const int b_off = (c & 1) * B_BYTES + b_addr0;
+      __syncthreads();  // the stages of step c landed for every wave; everyone finished reading the stages of step c-1
+      if (c + 1 < nv) issue_skip(c + 1);
+      const int a_off = stage_a(c) * 32768 + sa_addr0;
+      const int b_off = stage_b(c) * B_BYTES + b_addr0;
       if constexpr (IsSplit<T>::value) {
         // raw fp32 block input: split into bf16 hi / lo in registers (as conv_igemm's bf16x3 path)
 #pragma unroll
@@ -800,13 +821,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
 // range walked side by side -- is bit-identical and 1.5-3 % slower on every layer (128^2 256->256: 1011 vs 1027 TF/s, 512->256:
 // 1199 vs 1218): the barrier between tiles and ~100 scalar spills of the hoisted launch constants cost more than the
 // workgroup dispatch it saves.)
-template <typename T, bool LO = false, bool LOIN = false>
+template <typename T, bool LO = false, bool LOIN = false, bool SKS = false>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
-  fused_tile<T, LO, LOIN>(p, xcd_remap(blockIdx.x, p.ntiles_total));
+  fused_tile<T, LO, LOIN, SKS>(p, xcd_remap(blockIdx.x, p.ntiles_total));
 }
 
-template <typename T, bool LO = false, bool LOIN = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T, LO, LOIN>;
+template <typename T, bool LO = false, bool LOIN = false, bool SKS = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T, LO, LOIN, SKS>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -819,13 +840,15 @@ template <typename T, bool LO = false, bool LOIN = false> int launch_fused(const
 
 }  // namespace
 
-// with optional lo planes of the output and the residual source (compensated 16-bit storage, precision mode fp16c)
-extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+// with optional lo planes of the output and the residual source (compensated 16-bit storage, precision mode fp16c) and,
+// optionally, the 1x1 skip phase in split precision (skip_weight_lo != NULL: lo planes of the skip sources + the lo part of
+// the skip weights, precision mode fp16s)
+extern "C" int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
                                       int C1, const float* ab, int up,
                                       const void* weight, const float* bias, void* out, void* out_lo, const void* res,
                                       const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
                                       const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
-                                      void* stream) {
+                                      const void* skip0_lo, const void* skip1_lo, const void* skip_weight_lo, void* stream) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
@@ -855,6 +878,12 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* s
   if (any_lo && esz != 2) return ivid_set_error("conv3x3_gn: lo planes need a 16-bit dtype", hipSuccess);
   if (src1_lo && C1 <= 0) return ivid_set_error("conv3x3_gn: src1_lo without src1", hipSuccess);
   if (res_lo && !res_mode) return ivid_set_error("conv3x3_gn: res_lo without a residual", hipSuccess);
+  if (skip_weight_lo) {
+    if (esz != 2 || dtype != IVID_F16) return ivid_set_error("conv3x3_gn: the split skip phase is an fp16 instantiation", hipSuccess);
+    if (skipC0 <= 0 || !skip0_lo || (skipC1 > 0 && !skip1_lo))
+      return ivid_set_error("conv3x3_gn: the split skip phase needs a lo plane of every skip source", hipSuccess);
+    if (narrow) return ivid_set_error("conv3x3_gn: the split skip phase exists in the 256-wide kernel only (Cout > 128)", hipSuccess);
+  }
   if (narrow)
     return ivid_fused128_launch(dtype, src0, C0, src1, C1, ab, up, weight, bias, out, res, res_mode, N, H, W, Cout, stats, skip0,
                                 skipC0, skip1, skipC1, skip_weight, stream, out_lo, res_lo, src0_lo, src1_lo);
@@ -867,9 +896,14 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* s
   a.ntiles_total = N * a.tiles_x * a.tiles_y * a.ntiles_n;
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
   a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo; a.src0_lo = (const char*)src0_lo; a.src1_lo = (const char*)src1_lo;
+  a.sk0_lo = (const char*)skip0_lo; a.sk1_lo = (const char*)skip1_lo; a.skw_lo = (const char*)skip_weight_lo;
 #ifdef IVID_DEV_TIMELINE
   a.dbg = g_timeline;
 #endif
+  if (skip_weight_lo) {
+    if (src0_lo || src1_lo) return launch_fused<_Float16, true, true, true>(a, (hipStream_t)stream);
+    return launch_fused<_Float16, true, false, true>(a, (hipStream_t)stream);
+  }
   if (src0_lo || src1_lo) {
     if (dtype == IVID_BF16) return launch_fused<__bf16, true, true>(a, (hipStream_t)stream);
     return launch_fused<_Float16, true, true>(a, (hipStream_t)stream);
@@ -882,6 +916,16 @@ extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* s
   if (dtype == IVID_F16) return launch_fused<_Float16>(a, (hipStream_t)stream);
   if (dtype == IVID_BF16X3) return launch_fused<bf16x3_t>(a, (hipStream_t)stream);
   return launch_fused<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int ivid_conv3x3_gn_skip_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                                      int C1, const float* ab, int up,
+                                      const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                                      const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
+                                      const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
+                                      void* stream) {
+  return ivid_conv3x3_gn_skip_s(dtype, src0, src0_lo, C0, src1, src1_lo, C1, ab, up, weight, bias, out, out_lo, res, res_lo, res_mode,
+                                N, H, W, Cout, stats, skip0, skipC0, skip1, skipC1, skip_weight, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int ivid_conv3x3_gn_skip(int dtype, const void* src0, int C0, const void* src1, int C1, const float* ab, int up,

@@ -198,6 +198,43 @@ __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ s
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
+// fp32 NHWC tensor -> two 16-bit planes hi = T(x), lo = T(x - hi) (the compensated storage of the fp16c / fp16s modes).  Used where
+// an island of split-precision layers (fp32 storage, three MFMA passes per product) hands its tensors to the 16-bit part
+// of the network (precision mode fp16s: the first encoder level).
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_hilo_kernel(const f32x4* __restrict__ src, char* __restrict__ hi,
+                                                          char* __restrict__ lo, long long n8) {
+  typedef typename Elem<T>::vec vec_t;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const f32x4 a = src[2 * i], b = src[2 * i + 1];
+    float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}, g[8];
+    const vec_t h = f32_to_vec<T>(f);
+    vec_to_f32<T>(h, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = f[e] - g[e];
+    *(vec_t*)(hi + i * 16) = h;
+    *(vec_t*)(lo + i * 16) = f32_to_vec<T>(g);
+  }
+}
+
+extern "C" int ivid_f32_to_hilo(int dtype, const float* src, void* hi, void* lo, long long n, void* stream) {
+  if (dtype != IVID_F16 && dtype != IVID_BF16) return ivid_set_error("f32_to_hilo: needs a 16-bit dtype", hipSuccess);
+  if (n < 0 || n % 8 || !src || !hi || !lo || ((uintptr_t)src | (uintptr_t)hi | (uintptr_t)lo) % 16)
+    return ivid_set_error("f32_to_hilo: n % 8 == 0 and 16-byte aligned pointers", hipSuccess);
+  if (!n) return 0;
+  const long long n8 = n / 8;
+  long long blocks = (n8 + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (dtype == IVID_F16)
+    hipLaunchKernelGGL(f32_to_hilo_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
+                       (char*)hi, (char*)lo, n8);
+  else
+    hipLaunchKernelGGL(f32_to_hilo_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src,
+                       (char*)hi, (char*)lo, n8);
+  return ivid_check_launch("f32_to_hilo");
+}
+
 // Device copy of `bytes` (a multiple of 16, both pointers 16-byte aligned).  Used by the stacked classifier-free-guidance
 // forward: up to the first FiLM (adm.py:214-218) the conditional and the unconditional half of the batch see identical inputs
 // (same x, same t, no class dependence before the embedding is applied), so the first ResBlock's in_layers convolution runs on

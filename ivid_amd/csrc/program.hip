@@ -73,6 +73,12 @@ int run_op(const Op& o, void* s) {
     case IVID_OP_CONV3X3_GN_SKIP_C:
       return ivid_conv3x3_gn_skip_c(I(0), CP(1), CP(2), I(3), CP(4), CP(5), I(6), CFP(7), I(8), CP(9), CFP(10), P(11), P(12), CP(13),
                                     CP(14), I(15), I(16), I(17), I(18), I(19), FP(20), CP(21), I(22), CP(23), I(24), CP(25), s);
+    case IVID_OP_CONV3X3_GN_SKIP_S:
+      return ivid_conv3x3_gn_skip_s(I(0), CP(1), CP(2), I(3), CP(4), CP(5), I(6), CFP(7), I(8), CP(9), CFP(10), P(11), P(12), CP(13),
+                                    CP(14), I(15), I(16), I(17), I(18), I(19), FP(20), CP(21), I(22), CP(23), I(24), CP(25), CP(26),
+                                    CP(27), CP(28), s);
+    case IVID_OP_F32_TO_HILO:
+      return ivid_f32_to_hilo(I(0), CFP(1), P(2), P(3), o.a[4].i, s);
     case IVID_OP_GN_APPLY_C:
       return ivid_gn_apply_c(I(0), CP(1), CP(2), I(3), CP(4), CP(5), I(6), CFP(7), P(8), I(9), I(10), I(11), I(12), I(13), s);
     case IVID_OP_CONV3X3_GN_OUT_C:

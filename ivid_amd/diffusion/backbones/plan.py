@@ -58,31 +58,58 @@ def _pad_to(c, m):
     return (c + m - 1) // m * m
 
 
+def island_stages(spec: UNetSpec):
+    """Indices (into spec.stages) of the encoder stages in front of the first down-sampling ResBlock: with the stem they form
+    the split-precision island of the fp16s mode.  Their outputs are the youngest states of the residual trunk (the stem
+    output plus one or two branches) and they reach the decoder's last blocks directly through the skip stash
+    (adm.py:557-563), so the operand roundings of their convolutions are the ones the output sees least damped."""
+    out = []
+    for i, st in enumerate(spec.stages):
+        if st.conv_in:
+            continue
+        if st.kind != "in" or any(isinstance(o, Res) and o.mode == "down" for o in st.ops):
+            break
+        out.append(i)
+    return out
+
+
 class PackedWeights:
     """Weights repacked once into the kernels' layouts: conv [Cout][tap][Cin] in the compute dtype,
     Linear / GroupNorm / bias / embedding tables in fp32, all emb_layers fused into one matrix."""
 
     def __init__(self, spec: UNetSpec, sd, device, dtype, comp=False):
         self.dtype = dtype
-        self.comp = int(comp)      # 1: precision mode fp16c (compensated trunk storage, split stem and head); 2: fp16cx (+ input lo planes)
+        # 1: precision mode fp16c (compensated trunk storage, split stem and head); 2: fp16cx (+ input lo planes);
+        # 3: fp16s (+ split-precision 1x1 skip convolutions; stem + first encoder level as a bf16x3 island)
+        self.comp = int(comp)
         assert not comp or _lib.esz(dtype) == 2
         tdt = _TORCH_DT[dtype]
         self.kstep = 128 // _lib.esz(dtype)
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
         t = {}
         # matrix operand of the MFMA kernels: compute dtype, or the hi/lo split form of the bf16x3 mode
-        mat = (lambda w: split_pack(w.contiguous())) if dtype == _lib.BF16X3 else (lambda w: w.to(tdt).contiguous())
+        mat_split = lambda w: split_pack(w.contiguous())
+        mat = mat_split if dtype == _lib.BF16X3 else (lambda w: w.to(tdt).contiguous())
+        self.island = set(island_stages(spec)) if self.comp >= 3 else set()
+        isl = {o.prefix for i in self.island for o in spec.stages[i].ops}    # ops whose weights take the bf16x3 layout
 
         def conv3(name, pad_cin=None):
             w = g(name + ".weight").permute(0, 2, 3, 1)  # [Cout,3,3,Cin]
             if pad_cin is not None and pad_cin != w.shape[-1]:
                 w = torch.nn.functional.pad(w, (0, pad_cin - w.shape[-1]))
-            t[name + ".weight"] = mat(w.reshape(w.shape[0], -1))
+            m = mat_split if name.rsplit(".", 2)[0] in isl else mat
+            t[name + ".weight"] = m(w.reshape(w.shape[0], -1))
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
         def conv1(name):
             w = g(name + ".weight")
-            t[name + ".weight"] = mat(w.reshape(w.shape[0], -1))
+            w2 = w.reshape(w.shape[0], -1)
+            if name.rsplit(".", 1)[0] in isl:
+                t[name + ".weight"] = mat_split(w2)
+            else:
+                t[name + ".weight"] = mat(w2)
+                if self.comp >= 3 and name.endswith(".skip_connection"):   # lo part for the split-precision skip phase
+                    t[name + ".weight_lo"] = hi_lo(w2, tdt)[1].contiguous()
             t[name + ".bias"] = g(name + ".bias").contiguous()
 
         def vec(name):
@@ -91,7 +118,10 @@ class PackedWeights:
 
         # stem: the 3x3 patch of the few input channels is ONE K row (k = tap*Cin + c, ivid_stem_im2col), padded to a K-step
         ws = g("input_blocks.0.0.weight").permute(0, 2, 3, 1).reshape(spec.stem_out, -1)   # [Cout, 9*Cin]
-        if comp:   # split stem (ivid_stem_im2col_split): K row [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]
+        if self.comp >= 3:   # the stem opens the bf16x3 island: plain im2col row, weights in the hi/lo split layout (K-step 32)
+            self.stem_k = _pad_to(9 * spec.in_channels, 32)
+            t["input_blocks.0.0.weight"] = mat_split(torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])))
+        elif comp:   # split stem (ivid_stem_im2col_split): K row [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]
             self.stem_k = _pad_to(27 * spec.in_channels, self.kstep)
             whi, wlo = hi_lo(ws, tdt)
             w3 = torch.cat([whi, whi, wlo], dim=1)
@@ -202,6 +232,8 @@ class UNetPlan:
         self.dtype = weights.dtype
         self.comp = weights.comp
         self.comp_in = weights.comp >= 2     # fp16cx: lo planes feed the fused halo transform; h1 is compensated too
+        self.split_skip = weights.comp >= 3  # fp16s: 1x1 skip convolutions in split precision (x_hi.w_hi + x_lo.w_hi + x_hi.w_lo)
+        self._main_mode = (self.dtype, self.comp, self.comp_in, self.split_skip)
         self.esz = _lib.esz(self.dtype)
         self.bsrc = bsrc
         self.n = 2 * bsrc if stacked else bsrc
@@ -239,6 +271,24 @@ class UNetPlan:
         _lib.call("ivid_unet_bind", h, self.x_in.data_ptr(), self.x_in.numel() * 4, self.t_in.data_ptr(),
                   self.c_in.data_ptr() if has_cls else None, self.bsrc, self.out.data_ptr(), self.out.numel() * 4)
         self.program = h
+
+    # ---- fp16s: the split-precision island (stem + first encoder level run as the bf16x3 mode would: fp32 storage) ----
+    def _set_island(self, on):
+        if on:
+            self.dtype, self.comp, self.comp_in, self.split_skip = _lib.BF16X3, 0, False, False
+        else:
+            self.dtype, self.comp, self.comp_in, self.split_skip = self._main_mode
+        self.esz = _lib.esz(self.dtype)
+
+    def _to16(self, a):
+        """fp32 island tensor -> the compensated 16-bit storage form (hi + lo planes) of the main mode; the GroupNorm partials
+        its producer wrote move over unchanged (they describe the same values up to 2^-22)."""
+        assert self.dtype != _lib.BF16X3
+        y = self._new(a.n, a.side, a.c, trunk=True)
+        y.stats, y.stats_blk, a.stats = a.stats, a.stats_blk, None
+        self._rec("ivid_f32_to_hilo", self.dtype, a.ptr, y.ptr, y.lo_ptr, a.n * a.side * a.side * a.c)
+        self._free(a)
+        return y
 
     # ---- launch recording ----
     def _rec(self, name, *args):
@@ -278,20 +328,21 @@ class UNetPlan:
             self.arena.put(act.stats)
 
     def _conv(self, dtype, src0, c0, src1, c1, wname, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
-              stats=None, out_act=None, out_lo=None, res_lo=None):
+              stats=None, out_act=None, out_lo=None, res_lo=None, wkey=".weight", no_bias=False):
         if out_act is not None and out_act.stats is not None:
             stats = out_act.stats
             out_act.stats_blk = self.lib.ivid_conv2d_stats_block(n, h, w, cout, self.tile_cfg)
         tile = self.tile_cfg
         if tile == 0 and taps == 1 and self._tile_1x1:
             tile = self._tile_1x1          # tuning hook (IVID_TILE_1X1): tile of the pointwise convolutions
+        bias = None if no_bias else self.w[wname + ".bias"].data_ptr()
         if out_lo is not None or res_lo is not None:
-            self._rec("ivid_conv2d_c", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
-                      self.w[wname + ".bias"].data_ptr(), out_ptr, out_lo, res_ptr, res_lo, res_mode, out_mode, n, h, w, cout,
+            self._rec("ivid_conv2d_c", dtype, src0, c0, src1, c1, self.w[wname + wkey].data_ptr(),
+                      bias, out_ptr, out_lo, res_ptr, res_lo, res_mode, out_mode, n, h, w, cout,
                       taps, tile, stats.data_ptr() if stats is not None else None)
             return
-        self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + ".weight"].data_ptr(),
-                  self.w[wname + ".bias"].data_ptr(), out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
+        self._rec("ivid_conv2d", dtype, src0, c0, src1, c1, self.w[wname + wkey].data_ptr(),
+                  bias, out_ptr, res_ptr, res_mode, out_mode, n, h, w, cout, taps,
                   tile, stats.data_ptr() if stats is not None else None)
 
     def _linear(self, x, k, wname, out, cout, res=None):
@@ -358,12 +409,18 @@ class UNetPlan:
                 if key not in self._sum_bias:
                     self._sum_bias[key] = (self.w[wname + ".bias"] + self.w[sname + ".bias"]).contiguous()
                 bias = self._sum_bias[key]
-            self._rec("ivid_conv3x3_gn_skip_c", self.dtype, x0.ptr, lo0, x0.c, x1.ptr if x1 is not None else None, lo1,
-                      x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
-                      bias.data_ptr(), out.ptr, out.lo_ptr, res_ptr, res_lo, res_mode, out.n, out.side, out.side, out.c, st,
-                      s0.ptr if s0 is not None else None, s0.c if s0 is not None else 0,
-                      s1.ptr if s1 is not None else None, s1.c if s1 is not None else 0,
-                      self.w[sname + ".weight"].data_ptr() if sname is not None else None)
+            args = (self.dtype, x0.ptr, lo0, x0.c, x1.ptr if x1 is not None else None, lo1,
+                    x1.c if x1 is not None else 0, ab.data_ptr(), 1 if up else 0, self.w[wname + ".weight"].data_ptr(),
+                    bias.data_ptr(), out.ptr, out.lo_ptr, res_ptr, res_lo, res_mode, out.n, out.side, out.side, out.c, st,
+                    s0.ptr if s0 is not None else None, s0.c if s0 is not None else 0,
+                    s1.ptr if s1 is not None else None, s1.c if s1 is not None else 0,
+                    self.w[sname + ".weight"].data_ptr() if sname is not None else None)
+            if skip is not None and self.split_skip:   # x_hi.w_hi + x_lo.w_hi + x_hi.w_lo inside the kernel's skip phase
+                assert s0.lo is not None and (s1 is None or s1.lo is not None)
+                self._rec("ivid_conv3x3_gn_skip_s", *args, s0.lo_ptr, s1.lo_ptr if s1 is not None else None,
+                          self.w[sname + ".weight_lo"].data_ptr())
+            else:
+                self._rec("ivid_conv3x3_gn_skip_c", *args)
             return
         if skip is None:
             self._rec("ivid_conv3x3_gn", self.dtype, x0.ptr, x0.c, x1.ptr if x1 is not None else None,
@@ -445,7 +502,8 @@ class UNetPlan:
         if op.cout <= 128:
             kstep //= 2                                       # the 128-wide variant works on 64-byte chunks
         if (fused2 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
-                and (skip is None or skip.c % kstep == 0)):
+                and (skip is None or skip.c % kstep == 0)
+                and not (self.split_skip and op.cout <= 128)):   # the split skip phase exists in the 256-wide kernel only
             # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
             # residual round trip)
             assert op.mode == "same"
@@ -457,8 +515,19 @@ class UNetPlan:
         if op.has_skip_conv:
             assert op.mode == "same"
             r = self._new(n, so, op.cout, trunk=True)   # skip_connection(x) is a term of the residual stream
-            self._conv(self.dtype, x.ptr, x.c, skip.ptr if skip is not None else None, skip.c if skip is not None else 0,
-                       op.prefix + ".skip_connection", r.ptr, None, 0, 0, n, so, so, op.cout, 1, out_lo=r.lo_ptr)
+            sc = skip.c if skip is not None else 0
+            sname = op.prefix + ".skip_connection"
+            self._conv(self.dtype, x.ptr, x.c, skip.ptr if skip is not None else None, sc,
+                       sname, r.ptr, None, 0, 0, n, so, so, op.cout, 1, out_lo=r.lo_ptr)
+            if self.split_skip:
+                # split precision as three chained launches (each result is carried as hi + lo, 2^-22): + x_lo.w_hi, + x_hi.w_lo
+                assert x.lo is not None and (skip is None or skip.lo is not None)
+                r2 = self._new(n, so, op.cout, trunk=True)
+                self._conv(self.dtype, x.lo_ptr, x.c, skip.lo_ptr if skip is not None else None, sc, sname, r2.ptr, r.ptr, 1, 0,
+                           n, so, so, op.cout, 1, out_lo=r2.lo_ptr, res_lo=r.lo_ptr, no_bias=True)
+                self._conv(self.dtype, x.ptr, x.c, skip.ptr if skip is not None else None, sc, sname, r.ptr, r2.ptr, 1, 0,
+                           n, so, so, op.cout, 1, out_lo=r.lo_ptr, res_lo=r2.lo_ptr, wkey=".weight_lo", no_bias=True)
+                self._free(r2)
             res_ptr, res_lo, res_mode = r.ptr, r.lo_ptr, 1
         else:
             assert skip is None
@@ -512,6 +581,9 @@ class UNetPlan:
         self._linear(semb, ed, "emb_all", self.embproj, sp.emb_total)
         # ---- stem ----
         S = sp.image_size
+        island = sorted(w.island)
+        if island:
+            self._set_island(True)
         xin = self._new(n, S, w.stem_k)
         self._rec("ivid_stem_im2col_split" if self.comp else "ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n,
                   sp.in_channels, S, S, w.stem_k, xin.ptr)
@@ -522,9 +594,15 @@ class UNetPlan:
         self._tap("stem", h)
         stash = [h]
         # ---- encoder / bottleneck / decoder ----
-        for st in sp.stages:
+        for si, st in enumerate(sp.stages):
             if st.conv_in:
                 continue
+            if island and si == island[-1] + 1:
+                # leaving the island: its tensors (all of them are in the skip stash; the last one is also the next block's
+                # input) change to the compensated 16-bit storage of the main mode
+                self._set_island(False)
+                stash = [self._to16(a) for a in stash]
+                h = stash[-1]
             skip = stash.pop() if st.kind == "out" else None
             first = True
             for op in st.ops:

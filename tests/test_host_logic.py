@@ -163,8 +163,8 @@ def test_unsupported_attention_geometry_is_refused_at_construction():
 def test_precision_names_and_reference_fp16_api():
     from ivid_amd import _lib
     from ivid_amd.diffusion.backbones import AdmUnet2d
-    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2}
-    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2}
+    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2}
+    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3}
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
