@@ -308,3 +308,86 @@ def test_stem_split_reproduces_the_unrounded_convolution(dtype, cin):
     e = common.rel_l2(joined(out, out_lo), ref)
     G.report(f"stem_split/{G.DN[dtype]}/cin{cin}", rel_l2=e)
     assert e < (1e-4 if dtype == 1 else 5e-6), e
+
+
+SKIP_S = [
+    # name, N, H, W, C0 (conv input), Cout, res... none; skip channels (S0, S1); in_lo
+    ("skip_cat_256+256_c256_like_ob12", 2, 32, 32, 128, 256, (256, 256), True),
+    ("skip_single_192_c192", 1, 16, 64, 64, 192, (192, 0), False),
+    ("skip_cat_128+64_c320_two_ntiles", 2, 8, 32, 64, 320, (128, 64), True),
+]
+
+
+@pytest.mark.parametrize("case", SKIP_S, ids=[c[0] for c in SKIP_S])
+def test_conv3x3_gn_skip_s_split_precision_skip_phase(case):
+    """ivid_conv3x3_gn_skip_s (precision mode fp16s): the 1x1 skip_connection term of the output (adm.py:190,222) must reproduce
+    conv1x1(UNROUNDED x = hi + lo, UNROUNDED w) to ~2^-20 -- x_hi.w_hi + x_lo.w_hi + x_hi.w_lo -- where ivid_conv3x3_gn_skip_c
+    (one MFMA pass on x_hi, w_hi) is 2^-11 off.  The 3x3 part keeps its single fp16 pass in both (same operands in the reference)."""
+    name, N, H, W, C0, Cout, (S0, S1), in_lo = case
+    dtype = 2
+    L = G.lib()
+    s = sum(map(ord, name)) % 1000
+    x0 = common.seeded_randn(s, N, C0, H, W) * 3.0
+    a = 0.5 + 0.5 * torch.rand(N, C0, generator=torch.Generator().manual_seed(s))
+    b = 0.3 * common.seeded_randn(s + 2, N, C0)
+    w = common.seeded_randn(s + 3, Cout, C0, 3, 3) / np.sqrt(C0 * 9) * 0.05          # small 3x3 branch: the skip term dominates
+    bias = common.seeded_randn(s + 4, Cout) * 0.1
+    d0, d0l, x0v = planes(x0, dtype) if in_lo else (G.to_nhwc(x0, dtype), None, G.rounded(x0, dtype))
+    act = G.rounded(F.silu(x0v * a[:, :, None, None] + b[:, :, None, None]), dtype)
+    ref3 = F.conv2d(act.double(), G.rounded(w, dtype).double(), bias.double(), padding=1)
+    k0 = common.seeded_randn(s + 6, N, S0, H, W) * 4.0
+    k1 = common.seeded_randn(s + 7, N, S1, H, W) * 2.0 if S1 else None
+    wk = common.seeded_randn(s + 8, Cout, S0 + S1, 1, 1) / np.sqrt(S0 + S1)
+    k0h, k0l, k0v = planes(k0, dtype)
+    k1h, k1l, k1v = planes(k1, dtype) if k1 is not None else (None, None, None)
+    kv = k0v if k1 is None else torch.cat([k0v, k1v], 1)
+    ref_exact = ref3 + F.conv2d(kv.double(), wk.double())                                               # unrounded skip operands
+    ref_single = ref3 + F.conv2d(G.rounded(kv, dtype).double(), G.rounded(wk, dtype).double())          # one fp16 pass
+    t = G.tdt(dtype)
+    wk2 = wk.reshape(Cout, -1)
+    wkh = wk2.to(t)
+    wkl = (wk2 - wkh.float()).to(t)
+    wkhd, wkld = wkh.cuda(), wkl.cuda()
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    bd = bias.cuda()
+    outs = {}
+    for split in (True, False):
+        out = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=t)
+        out_lo = torch.full_like(out, float("nan"))
+        stats = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
+        L.call("ivid_conv3x3_gn_skip_s", dtype, L.ptr(d0), L.ptr(d0l), C0, None, None, 0, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out),
+               L.ptr(out_lo), None, None, 0, N, H, W, Cout, L.ptr(stats), L.ptr(k0h), S0, L.ptr(k1h), S1, L.ptr(wkhd),
+               L.ptr(k0l) if split else None, L.ptr(k1l) if split else None, L.ptr(wkld) if split else None, G.stream())
+        torch.cuda.synchronize()
+        outs[split] = joined(out, out_lo)
+        assert torch.isfinite(outs[split]).all()
+        o = (out.float() + out_lo.float()).reshape(N, H // 4, 4, W // 32, 32, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 128, Cout)
+        sref = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+        assert float((stats - sref).abs().max() / sref.abs().max()) < 1e-5
+    e_split, e_single = common.rel_l2(outs[True], ref_exact.float()), common.rel_l2(outs[False], ref_exact.float())
+    e_single_own = common.rel_l2(outs[False], ref_single.float())
+    G.report(f"conv3x3_gn_skip_s/{name}", rel_l2_split_vs_exact=e_split, rel_l2_single_pass_vs_exact=e_single,
+             rel_l2_single_pass_vs_its_own_operands=e_single_own)
+    assert e_single_own < 2e-5            # skip_weight_lo == NULL is ivid_conv3x3_gn_skip_c
+    assert e_split < 1.5e-5, e_split      # w_lo is an fp16 subnormal for small weights: ~2^-20 instead of 2^-22
+    assert e_single > 10 * e_split, (e_single, e_split)
+    # refused where the split phase does not exist
+    assert L.load().ivid_conv3x3_gn_skip_s(dtype, L.ptr(d0), None, C0, None, None, 0, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(out_lo),
+                                           None, None, 0, N, H, W, Cout, None, L.ptr(k0h), S0, L.ptr(k1h), S1, L.ptr(wkhd), None, None,
+                                           L.ptr(wkld), G.stream()) != 0      # lo weights without lo planes of the sources
+
+
+@pytest.mark.parametrize("dtype", DT16)
+def test_f32_to_hilo_planes(dtype):
+    L = G.lib()
+    x = (common.seeded_randn(5, 3, 17, 8, 64) * 7.0).cuda()
+    t = G.tdt(dtype)
+    hi = torch.full(x.shape, float("nan"), device="cuda", dtype=t)
+    lo = torch.full_like(hi, float("nan"))
+    L.call("ivid_f32_to_hilo", dtype, L.ptr(x), L.ptr(hi), L.ptr(lo), x.numel(), G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(hi, x.to(t)) and torch.equal(lo, (x - x.to(t).float()).to(t))
+    assert common.rel_l2(hi.float() + lo.float(), x) < (1.5e-5 if dtype == 1 else 1e-6)
+    assert L.load().ivid_f32_to_hilo(0, L.ptr(x), L.ptr(hi), L.ptr(lo), x.numel(), G.stream()) != 0
+    assert L.load().ivid_f32_to_hilo(dtype, L.ptr(x), L.ptr(hi), L.ptr(lo), 12, G.stream()) != 0

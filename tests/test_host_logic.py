@@ -169,9 +169,9 @@ def test_precision_names_and_reference_fp16_api():
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16c" and m.dtype == torch.float16          # adm.py:333: the reference's attribute
+    assert m.precision == "fp16s" and m.dtype == torch.float16          # adm.py:333: the reference's attribute
     m.convert_to_fp32(); assert m.precision == "fp32"
-    m.convert_to_fp16(); assert m.precision == "fp16c"
+    m.convert_to_fp16(); assert m.precision == "fp16s"
     m.set_precision("bf16x3"); assert m.precision == "bf16x3"
     with pytest.raises(ValueError):
         m.set_precision("int8")

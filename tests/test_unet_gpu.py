@@ -2,10 +2,13 @@
 AdmUnet2d forward, stacked CFG forward, DDIM / DDPM / inpaint chains — against the committed golden
 fixtures (outputs of the live reference) and the oracle on the same seeded inputs.
 
-Bars (rel-L2 of one forward vs the reference's fp32 output): fp32, bf16x3 and fp16c (fp16 MFMA with compensated
-storage, the bench headline) <= 1e-3 as BASELINE.json's north_star states (measured ~1e-6 / ~1e-5 / ~8.7e-4);
-plain fp16 <= 1.5e-3 (measured 1.07-1.25e-3; the reference's own fp16 torso is 1.3-1.5e-3 from its fp32 path);
-bf16 <= 1.2e-2 (measured 8.0e-3 - 1.0e-2).  Every measured value is written to gpurun_out/parity_report.json.
+Bars (rel-L2 of one forward vs the reference's fp32 output).  On the REPRESENTATIVE FORWARD SET (round 4: q-sampled scenes
+at t in {0, 20, 250, 500, 750, 999}, reference outputs in tests/golden/*_fwd_set.npz) the bar is on the MAXIMUM over the set:
+fp32, bf16x3 <= 1e-4; fp16s (fp16 MFMA; split-precision skip convolutions and first encoder level: the bench headline)
+<= 9.5e-4, i.e. BASELINE.json's 1e-3 with 5 % margin (measured 8.8e-4 / 8.3e-4); fp16cx / fp16c / fp16 are measured and
+reported there (1.45e-3 / 1.66e-3 / 2.06e-3 on clean smooth inputs at small t: OUTSIDE the tolerance).  On the pure-noise
+t = 999 input of rounds 1-3 the old bars stay: fp16c / fp16cx <= 1e-3, plain fp16 <= 1.5e-3, bf16 <= 1.2e-2.
+Every measured value is written to gpurun_out/parity_report.json.
 """
 import pytest
 import torch
@@ -17,7 +20,9 @@ from oracle import adm_oracle, sampler_oracle
 pytestmark = pytest.mark.gpu
 PARITY_BAR = 1e-3
 # precision -> bar on one forward's rel-L2 vs the reference fp32 output
-MODE_BAR = {"bf16": 1.2e-2, "fp16": 1.5e-3, "fp16c": PARITY_BAR, "fp16cx": PARITY_BAR, "bf16x3": PARITY_BAR}
+MODE_BAR = {"bf16": 1.2e-2, "fp16": 1.5e-3, "fp16c": PARITY_BAR, "fp16cx": PARITY_BAR, "fp16s": PARITY_BAR, "bf16x3": PARITY_BAR}
+# max over the representative forward set: the modes that claim BASELINE.json's tolerance per forward
+SET_BAR = {"fp32": 1e-4, "bf16x3": 1e-4, "fp16s": 9.5e-4}
 
 
 def build(args, seed, precision):
@@ -112,7 +117,7 @@ def test_stacked_cfg_forward_shares_the_class_independent_prefix_bit_exactly(pre
         assert ncopy[0] == 2 and ncopy[1] == 0, ncopy
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "fp16cx", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "fp16cx", "fp16s", "bf16x3"])
 @pytest.mark.parametrize("name,args,seed", [("mini_fwd", C.MINI, 0), ("mini_cond_fwd", C.MINI_COND, 2)])
 def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
     m, sd = build(args, seed, precision)
@@ -129,14 +134,15 @@ def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
 
 def test_use_fp16_config_selects_the_fp16_torso_like_the_reference():
     """adm.py:333,508-514: use_fp16 / convert_to_fp16() mean an fp16 torso (not bf16) -- here fp16 MFMA operands with the
-    compensated trunk (precision "fp16c": inside the 1e-3 tolerance of the fp32 path, which a plain fp16 torso is not)."""
+    compensated trunk, split-precision skip convolutions and first encoder level (precision "fp16s": inside the 1e-3 tolerance
+    of the fp32 path on the representative forward set, which a plain fp16 torso -- the reference's own included -- is not)."""
     from ivid_amd.diffusion.backbones import AdmUnet2d
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16c" and m.dtype == torch.float16
+    assert m.precision == "fp16s" and m.dtype == torch.float16
     m.convert_to_fp32()
     assert m.precision == "fp32"
     m.convert_to_fp16()
-    assert m.precision == "fp16c"
+    assert m.precision == "fp16s"
 
 
 def test_small128_forward_matches_reference_golden():
@@ -238,13 +244,13 @@ def test_config1_small128_ddim10_matches_reference_golden():
     G.report("chain/config1_bs2_fp32", samples=e, x0_first=C.rel_l2(res.pred_x_0[0].cpu(), g["x0_first"]))
     assert e < PARITY_BAR
     # the same chain in the MFMA-speed parity mode (split-bf16) and, reported, in the 16-bit modes
-    for prec in ("bf16x3", "fp16c", "fp16", "bf16"):
+    for prec in ("bf16x3", "fp16s", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
         torch.manual_seed(1)
         r2 = smp.sample(2, noise=x_T.cuda(), steps=10, verbose=False, noise_fn=_cpu_noise_fn())
         ep = C.rel_l2(r2.samples.cpu(), g["samples"])
         G.report("chain/config1_bs2_" + prec, samples=ep)
-        if prec in ("bf16x3", "fp16c"):
+        if prec in ("bf16x3", "fp16s", "fp16c"):
             assert ep < PARITY_BAR, ep
         else:
             assert ep < 10 * MODE_BAR[prec], (prec, ep)   # drift check of a 10-step chain
@@ -275,7 +281,7 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
     assert abs(float(x_T.double().sum()) - float(g["x_checksum"])) < 1e-6
     cls = torch.from_numpy(g["classes"]).cuda()
     errs = {}
-    for prec in ("fp32", "bf16x3", "fp16cx", "fp16c", "fp16", "bf16"):
+    for prec in ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
         torch.manual_seed(3)
         res = smp.sample(2, noise=x_T.cuda(), classes=cls, steps=int(g["steps"]), strength=float(g["strength"]), verbose=False,
@@ -287,9 +293,95 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
         assert torch.isfinite(res.samples).all()
     print("config 2 chain, samples rel-L2 vs the reference:", {k: v["samples"] for k, v in errs.items()})
     assert errs["fp32"]["samples"] < 1e-4
-    for prec in ("bf16x3", "fp16cx", "fp16c"):
+    for prec in ("bf16x3", "fp16s", "fp16cx", "fp16c"):
         assert errs[prec]["samples"] < PARITY_BAR, (prec, errs[prec])
     assert errs["fp16"]["samples"] < 10 * MODE_BAR["fp16"] and errs["bf16"]["samples"] < 10 * MODE_BAR["bf16"]
+
+
+def _forward_set(model_name, args, seed, gname):
+    """max / argmax over the representative forward set for every precision mode (tests/common.fwd_set_inputs)."""
+    g = C.load_golden(gname)
+    ins = C.fwd_set_inputs(args["in_channels"], args["image_size"])
+    for key, x, _, _ in ins:   # the seeded recipe rebuilds the generator's inputs
+        assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"])))
+    x = torch.cat([i[1] for i in ins]).cuda()
+    t = torch.tensor([i[2] for i in ins]).cuda()
+    has_cls = args["num_classes"] is not None
+    cls = torch.tensor([i[3] for i in ins]).cuda() if has_cls else None
+    m, _ = build(args, seed, "fp32")
+    out = {}
+    for prec in ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
+        m.set_precision(prec)
+        if has_cls:
+            ec, eu = [v.cpu() for v in m.forward_cfg(x, t, cls)]
+        else:
+            ec, eu = None, m(x, t, None).cpu()
+        rows = {}
+        for i, (key, _, _, _) in enumerate(ins):
+            if ec is not None:
+                rows[key + "_c"] = C.rel_l2(ec[i], g[key + "_c"])
+            rows[key + "_u"] = C.rel_l2(eu[i], g[key + "_u"])
+        worst = max(rows, key=rows.get)
+        out[prec] = rows[worst]
+        G.report(f"fwd_set/{model_name}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), **rows)
+    print(f"forward set {model_name}: max rel-L2 vs the reference per mode:", {k: "%.3e" % v for k, v in out.items()})
+    return out
+
+
+@pytest.mark.parametrize("model_name,args,seed,gname", [("large128", C.LARGE128, 4, "large128_fwd_set"),
+                                                        ("small128", C.SMALL128, 3, "small128_fwd_set")])
+def test_forward_set_max_deviation_per_mode(model_name, args, seed, gname):
+    """SURVEY.md 8(c) "full forward at t in {0, 20, 500, 999}": the inputs a sampling chain actually feeds the network --
+    x_t = the reference's q-sample of two synthetic RGBD scenes at six timesteps, both guidance branches -- against the live
+    reference's outputs (tests/golden/make_golden_fwd_set.py).  The headline claim: fp16s <= 9.5e-4 on EVERY input of the set;
+    fp16cx / fp16c / fp16 are measured (clean smooth inputs at t <= 20 put them at 1.4-2.1e-3: outside the tolerance)."""
+    e = _forward_set(model_name, args, seed, gname)
+    for prec, bar in SET_BAR.items():
+        assert e[prec] < bar, (prec, e[prec])
+    assert e["fp16s"] < e["fp16cx"] < e["fp16c"] < e["fp16"] < 3e-3, e
+    assert e["bf16"] < 3e-2
+
+
+def test_config2_teacher_forced_eps_on_the_chains_own_inputs():
+    """Per-step parity of BASELINE config 2, teacher-forced (hard part 8): the guided eps
+    (classifier_free_guidance.py:39-42) on the inputs the REFERENCE chain fed its model at steps 1, 10, 25 and 49
+    (tests/golden/large128_ddim50_cfg_steps.npz) -- the samples of a synthetic-weight chain are dominated by the first x0
+    estimate and cannot see the later steps."""
+    g = C.load_golden("large128_ddim50_cfg_steps")
+    m, _ = build(C.LARGE128, 4, "fp32")
+    cls = torch.from_numpy(g["classes"]).cuda()
+    errs = {}
+    for prec in ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
+        m.set_precision(prec)
+        errs[prec] = {}
+        for k in (1, 10, 25, 49):
+            x = torch.from_numpy(g[f"x_step{k}"]).cuda()
+            t = torch.full((x.shape[0],), int(g[f"t_step{k}"]), dtype=torch.long).cuda()
+            ec, eu = m.forward_cfg(x, t, cls)
+            errs[prec][f"step{k}"] = C.rel_l2((1.5 * ec - 0.5 * eu).cpu(), g[f"eps_step{k}"])
+        G.report("teacher_forced/config2_" + prec, **errs[prec])
+    print("config 2, teacher-forced guided eps:", {p: {k: "%.2e" % v for k, v in e.items()} for p, e in errs.items()})
+    for prec, bar in (("fp32", 1e-4), ("bf16x3", 1e-4), ("fp16s", PARITY_BAR)):
+        assert max(errs[prec].values()) < bar, (prec, errs[prec])
+
+
+def test_fp16s_plan_runs_the_first_level_as_a_split_island_and_every_skip_conv_in_split_precision():
+    """Structure of the fp16s launch plan: stem + first encoder level with fp32 storage (IVID_BF16X3 launches), three
+    ivid_f32_to_hilo hand-overs (stem output + the level's two ResBlocks), every 1x1 skip_connection either inside
+    ivid_conv3x3_gn_skip_s or as three chained ivid_conv2d_c launches (x_hi.w_hi, + x_lo.w_hi, + x_hi.w_lo)."""
+    from ivid_amd import _lib
+    m, _ = build(C.LARGE128, 4, "fp16s")
+    plan = m.plan(1, False)
+    names = [name for _, name, _ in plan.launches]
+    assert names.count("ivid_f32_to_hilo") == 3
+    first = names.index("ivid_f32_to_hilo")
+    island = [(n, a) for _, n, a in plan.launches[:first] if n in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip", "ivid_conv2d", "ivid_gn_apply")]
+    assert sum(1 for n, a in island if n == "ivid_conv3x3_gn" and a[0] == _lib.BF16X3) == 4        # two ResBlocks x two convs
+    assert not any(a[0] == _lib.BF16X3 for _, n, a in plan.launches[first:] if n.startswith("ivid_conv"))
+    skips = [op for op in m.spec.res_ops() if op.has_skip_conv]
+    fused = names.count("ivid_conv3x3_gn_skip_s")
+    chained = sum(1 for _, n, a in plan.launches if n == "ivid_conv2d_c" and a[6] is None)   # bias-free correction passes
+    assert fused + chained // 2 == len(skips) and chained % 2 == 0 and fused >= 9, (fused, chained, len(skips))
 
 
 def test_forward_deviation_on_a_structured_input_large128():
@@ -306,12 +398,13 @@ def test_forward_deviation_on_a_structured_input_large128():
     cls = torch.tensor([7])
     ref = adm_oracle.unet_forward(sd, C.LARGE128, x, t, cls)
     errs = {}
-    for prec in ("bf16x3", "fp16cx", "fp16c", "fp16", "bf16"):
+    for prec in ("bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
         errs[prec] = C.rel_l2(m(x.cuda(), t.cuda(), cls.cuda()).cpu(), ref)
     G.report("unet/large128_structured_input_t500", **errs)
     print("structured input, t = 500:", errs)
     assert errs["bf16x3"] < 1e-4
+    assert errs["fp16s"] < 9.5e-4 and errs["fp16s"] < errs["fp16cx"]
     assert errs["fp16cx"] < 1.05e-3 and errs["fp16c"] < 1.2e-3 and errs["fp16cx"] < errs["fp16c"] < errs["fp16"] < 1.6e-3
     assert errs["bf16"] < MODE_BAR["bf16"]
 
