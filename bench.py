@@ -326,7 +326,7 @@ def kernel_table(prof, precision):
             fl, _ = conv_flops(args)
             # a launch without bias is a correction pass of a split-precision 1x1 skip convolution (fp16s: + x_lo.w_hi,
             # + x_hi.w_lo): executed work, not algorithmic work
-            f["flop"] += fl if args[6] else 0.0
+            f["flop"] += fl if args[6] is not None else 0.0
             f["byt"] += conv_bytes(args, False)
         elif name == "ivid_conv3x3_up":
             f["flop"] += up_flops(args)

@@ -324,3 +324,13 @@ def test_bench_flop_accounting_adds_up_to_the_reference_count(monkeypatch):
     up = sum(bench.up_flops(a) for name, a, _ in prof if name == "ivid_conv3x3_up")
     executed = (launched - up * 5.0 / 9.0) / ref
     assert 0.92 < executed < 0.95, executed
+    # fp16s (the headline mode): the split-precision correction passes of the 1x1 skip convolutions and the three MFMA passes
+    # of the island are EXECUTED work, not algorithmic work -- the planned forward still adds up to the reference's count
+    pl = P.UNetPlan(spec, P.PackedWeights(spec, sd, "meta", _lib.F16, comp=3), "meta", bsrc, True)
+    prof = [(name, a, 1.0) for _fn, name, a in pl.launches]
+    names = [n for n, _, _ in prof]
+    assert names.count("ivid_f32_to_hilo") == 3 and names.count("ivid_conv3x3_gn_skip_s") >= 9
+    fam, other = bench.kernel_table(prof, "fp16s")
+    launched = sum(f["flop"] for f in fam.values())
+    assert abs((launched + shared) / ref - 1.0) < 5e-3, (launched + shared) / ref
+    assert "ivid_f32_to_hilo" in other
