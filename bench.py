@@ -270,14 +270,39 @@ def cached_pmc_traffic(precision):
     over this very command with --precision <mode>; scripts/gpu_pmc_bench.sh -> profiles/r03_pmc_traffic_<mode>.json, gfx950
     correction 2*FETCH + WRITE as MI355X_MICROARCH.md prescribes).  Collected in its own rocprofv3 invocation, NOT in the timed
     run; `csrc_sha` says whether the kernels are still the ones that were profiled."""
-    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s.json" % precision)
+    for rnd in ("r04", "r03"):
+        rel = "profiles/%s_pmc_traffic_%s.json" % (rnd, precision)
+        try:
+            d = json.load(open(os.path.join(ROOT, rel)))
+            return ({k: round(float(v), 0) for k, v in d["per_kernel_hbm_bytes_per_launch"].items()},
+                    {"file": rel, "commit": d.get("commit"), "kernels_unchanged_since": d.get("csrc_sha") == csrc_sha()})
+        except Exception:
+            continue
+    return {}, None
+
+
+def cached_pmc_mfma(precision):
+    """MFMA utilisation per kernel from the committed SQ counter pass (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE
+    over this very command with --precision <mode>; scripts/r4/gpu_pmc_mfma.sh -> profiles/r04_pmc_mfma_<mode>.json):
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = the share of all MFMA-pipe cycles that were
+    busy while the kernel ran, at the effective clock eff_clock_ghz the chip held (power-limited: < the 2.4 GHz of the nominal
+    peak); instantiations of one kernel are merged (their counters add)."""
+    rel = "profiles/r04_pmc_mfma_%s.json" % precision
     try:
-        d = json.load(open(f))
-        return ({k: round(float(v), 0) for k, v in d["per_kernel_hbm_bytes_per_launch"].items()},
-                {"file": "profiles/r03_pmc_traffic_%s.json" % precision, "commit": d.get("commit"),
-                 "kernels_unchanged_since": d.get("csrc_sha") == csrc_sha()})
+        d = json.load(open(os.path.join(ROOT, rel)))
     except Exception:
         return {}, None
+    out = {}
+    for fam in ("conv3x3_fused", "conv_igemm", "attn_kernel", "conv3x3_out"):
+        ks = {k: v for k, v in d["kernels"].items() if k == fam or k.startswith(fam + "<")}
+        busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in ks.values())
+        gui = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in ks.values()) / 8.0
+        sec = sum(v.get("seconds", 0.0) for v in ks.values())
+        if gui > 0 and sec > 0:
+            name = fam if fam.endswith("_kernel") else fam + "_kernel"
+            out[name] = {"mfma_busy_frac": round(busy / (1024.0 * gui), 4), "eff_clock_ghz": round(gui / sec / 1e9, 3),
+                         "by_instantiation": {k: v.get("mfma_busy_frac") for k, v in ks.items()}}
+    return out, {"file": rel, "commit": d.get("commit"), "kernels_unchanged_since": d.get("csrc_sha") == csrc_sha()}
 
 
 KERNEL_OF = {"ivid_conv3x3_gn": "conv3x3_fused_kernel", "ivid_conv3x3_gn_skip": "conv3x3_fused_kernel",
@@ -514,6 +539,8 @@ def main():
                                % (res_name, B, a.guidance if has_cls else 0.0, fwd_per_step, B * fwd_per_step),
                    "parallelism": "sample-parallel x%d (no collective in the denoise loop)" % world},
         "ranks_seen": ranks_seen,
+        "multi_gpu_note": "weak scaling by construction (sample-parallel, one weight broadcast, no collective in the loop); NO 1->8-GPU "
+                          "curve has been measured on hardware by anyone so far (the driver's SCALE runs of rounds 1-3 were skipped)",
         "denoise_steps_per_s": round(a.steps * world / dt, 4),
         "sample_fwd_per_s": round(fwd_s * B, 2),
         "job_tflops": round(job_tflops, 2),
@@ -542,10 +569,13 @@ def main():
                     "CFG halves sharing the first convolution); results are bit-identical / exact rewrites (DESIGN.md section 3)"}
         # HBM bytes per launch from the PMC passes of this command (their own rocprofv3 invocation, committed under profiles/)
         ct, ct_src = cached_pmc_traffic(a.precision) if (a.model == "large" and B == 64) else ({}, None)
+        cm, cm_src = cached_pmc_mfma(a.precision) if (a.model == "large" and B == 64) else ({}, None)
         for e in entries:
             if e["kernel"] in ct:
                 e["traffic"] = ct[e["kernel"]]
                 e["traffic_source"] = ct_src
+            if e["kernel"] in cm:
+                e["mfma_util"] = dict(cm[e["kernel"]], source=cm_src)
             if e["kernel"] == "conv_igemm_kernel":   # what the matrix pipe really does: the phase-form launches execute 4/9
                 ex = fam[e["kernel"]]["flop"] - up_alg * 5.0 / 9.0
                 e["executed_tflops"] = round(ex / (fam[e["kernel"]]["ms"] * 1e-3) / 1e12, 2)
@@ -553,7 +583,7 @@ def main():
         # `peak` is the nominal dense figure of MI355X_MICROARCH.md (2.4 GHz).  A pure register-resident MFMA stream on
         # random bf16 operands sustains only 1606 TFLOP/s on this chip (power-limited clock; scripts/micro/mfma_power.hip,
         # profiles/r01_mfma_power.txt) -- the ceiling this kernel actually works under:
-        if a.precision in ("bf16", "fp16", "fp16c", "fp16cx") and dom["bound"] == "mfma":
+        if a.precision in ("bf16", "fp16", "fp16c", "fp16cx", "fp16s") and dom["bound"] == "mfma":
             dom["power_limited_mfma_peak_random_operands"] = 1606.0
             dom["frac_of_power_limited_peak"] = round(dom["achieved"] / 1606.0, 4)
         result["roofline"] = dom

@@ -622,7 +622,8 @@ class UNetPlan:
                 stash.append(h)
         assert not stash
         # ---- head: GN + SiLU + conv3x3 -> fp32 NCHW (adm.py:565-566) ----
-        if (self.fuse_conv and S % 32 == 0 and sp.out_channels <= 16 and sp.final_c % (128 // self.esz) == 0
+        # (the split form of the compensated modes takes 1..8 output channels, the plain head 1..16)
+        if (self.fuse_conv and S % 32 == 0 and sp.out_channels <= (8 if self.comp else 16) and sp.final_c % (128 // self.esz) == 0
                 and os.environ.get("IVID_NO_FUSED_HEAD", "0") != "1"):
             ab = self._gn_coeffs(h, None, "out.0", None)      # one kernel: the input is read once
             if self.comp:

@@ -191,19 +191,20 @@ def main(argv=None):
         num_samples = len(seeds)
     # the reference draws random classes / cameras ONCE in the parent and passes the lists to every rank (sample.py:296-336):
     # here every rank draws them itself from one common seed, then takes its shard of the same lists
-    np.random.seed(parallel.common_draw_seed() % (1 << 32))
+    # (a local generator: the caller's global numpy RNG state is left alone)
+    draw = np.random.RandomState(parallel.common_draw_seed() % (1 << 32))
     classes = None
     num_classes = cfg_uncond["backbone"]["args"].get("num_classes")
     if num_classes is not None:
         if cfg.classes == "mod":
             classes = [seeds[i] % num_classes for i in range(num_samples)]
         elif cfg.classes == "random":
-            classes = [int(np.random.randint(num_classes)) for _ in range(num_samples)]
+            classes = [int(draw.randint(num_classes)) for _ in range(num_samples)]
         elif cfg.classes == "uniform":
             classes = [i % num_classes for i in range(num_samples)]
         else:
             classes = parse_int_list(cfg.classes)
-    modelviews = rgbd_3d.camera.viewset(cfg.viewset, num_samples)
+    modelviews = rgbd_3d.camera.viewset(cfg.viewset, num_samples, rng=draw)
 
     fw_uncond = build_model(cfg_uncond, cfg.ckpt_uncond, device, cfg.precision)
     fw_cond = build_model(cfg_cond, cfg.ckpt_cond, device, cfg.precision) if cfg.viewset != "uncond" else None

@@ -62,8 +62,8 @@ def spawn_one_process_per_gpu(script, argv, nproc=None, module=False):
     rc = subprocess.call(cmd, env=env)
     if rc != 0:
         print("[ivid_amd] the %d-rank launch failed (exit %d).  If torch.distributed / RCCL cannot initialise on this node, run a "
-              "single rank instead: WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 python -m %s ... (or CUDA_VISIBLE_DEVICES=<one gpu>)"
-              % (nproc, rc, script), file=sys.stderr)
+              "single rank instead: WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 python %s%s ... (or CUDA_VISIBLE_DEVICES=<one gpu>)"
+              % (nproc, rc, "-m " if module else "", script), file=sys.stderr)
     return rc
 
 

@@ -33,6 +33,9 @@ LARGE128 = dict(image_size=128, in_channels=4, out_channels=4, model_channels=25
                 dropout=0.0, use_fp16=False)
 
 
+# a class-conditional variant of the small-128 backbone (null class included): CFG chains at a CPU-affordable size
+SMALL128_CFG = dict(SMALL128, num_classes=1000, has_null_class=True)
+
 # rgbd_imagenet_adm_256_128_small_sr.json backbone (BASELINE config 5), fp32
 SR256 = dict(image_size=256, in_channels=8, out_channels=4, model_channels=128, num_res_blocks=2, num_classes=1000,
              has_null_class=True, channel_mult=[1, 1, 2, 3, 4], attention_resolutions=[64, 32, 16], num_groups=32,

@@ -87,6 +87,26 @@ def test_bench_launches_its_own_ranks():
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
 
 
+def test_bench_n1_prints_the_same_record_with_and_without_a_launcher():
+    """The driver's scaling run starts N = 1 under `torch.distributed.run --nproc-per-node 1` while its plain bench run starts
+    `python bench.py`: both must come up as the same single rank and print a record with the same keys, so that SCALE's N = 1
+    point can be checked against BENCH.  (CPU: the launcher dry run; the timed path needs an MI355X.)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(C.ROOT, "bench.py")
+    plain = subprocess.run([sys.executable, bench, "--gpus", "1", "--launcher-dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                               "127.0.0.1", "--master-port", "29731", bench, "--gpus", "1", "--launcher-dry-run"], env=env,
+                              capture_output=True, text=True, timeout=600)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a, b = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) for r in (plain, launched))
+    assert set(a) == set(b) and a["n_gpus"] == b["n_gpus"] == 1 and a["ranks_seen"] == b["ranks_seen"] == [[0, -1]]
+    assert a["config4_full_size_plan"] == b["config4_full_size_plan"]
+
+
 def test_spawn_helper_is_a_no_op_under_a_launcher_or_on_one_device():
     from ivid_amd import parallel
     assert parallel.spawn_one_process_per_gpu("x.py", [], nproc=1) is None

@@ -489,6 +489,94 @@ def test_sr256_forward_and_superres_chain_match_oracle():
     assert ours.shape == (2, 4, 64, 64) and e2 < PARITY_BAR
 
 
+CHAIN_MODES = ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16")
+CHAIN_CLAIM = ("fp32", "bf16x3", "fp16s")      # the modes that claim BASELINE.json's 1e-3 on the sampler's output
+
+
+def _chain_report(tag, errs):
+    for prec, e in errs.items():
+        G.report(f"chain16/{tag}_{prec}", **e)
+    print(f"{tag}: samples rel-L2 vs the reference per mode:", {k: "%.2e" % v["samples"] for k, v in errs.items()})
+    for prec in CHAIN_CLAIM:
+        assert errs[prec]["samples"] < PARITY_BAR, (tag, prec, errs[prec])
+    assert errs["fp32"]["samples"] < 1e-4, errs["fp32"]
+
+
+def test_ddpm_cfg3_chain_in_the_16bit_modes():
+    """The sampler setting of the unconditional first view of BASELINE configs 3 / 4 (inference/sample.py:44-47,79): DdpmSampler
+    (ancestral sampling) + ClassifierFreeGuidance strength 3.0 -- the guidance multiplies a forward's error by up to 1 + 2s = 7.
+    Golden: the live reference on a class-conditional small-128 backbone with a 250-timestep framework, bs 1
+    (tests/golden/make_golden_chains16.py); the ancestral noise is replayed from torch's seeded CPU generator."""
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("smallcfg_ddpm250_cfg3")
+    m, _ = build(C.SMALL128_CFG, 5, "fp32")
+    fw = frameworks.ClassifierFreeGuidance(m, timesteps=250, beta_schedule="linear", p_uncond=0.1)
+    smp = samplers.DdpmSampler(fw)
+    x_T = C.seeded_randn(311, 1, 4, 128, 128)
+    assert abs(float(x_T.double().sum()) - float(g["x_checksum"])) < 1e-6
+    cls = torch.from_numpy(g["classes"]).cuda()
+    errs = {}
+    for prec in CHAIN_MODES:
+        m.set_precision(prec)
+        torch.manual_seed(13)
+        res = smp.sample(1, noise=x_T.cuda(), classes=cls, strength=3.0, verbose=False, noise_fn=_cpu_noise_fn())
+        assert len(res.pred_x_0) == 250 and torch.isfinite(res.samples).all()
+        errs[prec] = dict(samples=C.rel_l2(res.samples.cpu(), g["samples"]), x0_first=C.rel_l2(res.pred_x_0[0].cpu(), g["x0_first"]),
+                          x0_mid=C.rel_l2(res.pred_x_0[125].cpu(), g["x0_mid"]), x0_last=C.rel_l2(res.pred_x_0[-1].cpu(), g["x0_last"]))
+    _chain_report("ddpm250_cfg3_smallcfg", errs)
+
+
+def test_inpaint_cfg3_ddim50_chain_on_the_scene_conditioning_in_the_16bit_modes():
+    """The sampler setting of every conditional view of BASELINE configs 3 / 4 (inference/sample.py:99-122): InpaintCFG strength
+    3.0 + DdimSampler 50 steps with replace_rgb 0.1 / replace_depth 0.2 / constrain_depth 0.5, on the conditioning the
+    reference's own aggregate_conditions produced for the scene fixture (86-89 % mask coverage).  Golden: the live reference,
+    mini 10-channel model at 128^2, bs 2 (tests/golden/make_golden_chains16.py)."""
+    import numpy as np
+    from ivid_amd.diffusion import frameworks, samplers
+    g, sc = C.load_golden("mini128cond_inpaint50"), C.load_golden("sample_all_scene_ref")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
+    color, depth = T(sc["cond_color"]), T(sc["cond_depth"])
+    mask, mask_rgb = T(sc["cond_mask"]).permute(0, 3, 1, 2).contiguous(), T(sc["cond_mask_rgb"]).permute(0, 3, 1, 2).contiguous()
+    convex = (T(sc["cond_depth_convex"]).permute(0, 3, 1, 2) * 2 - 1).contiguous()
+    y = torch.cat([color, depth], 1)
+    m, _ = build(C.MINI128_COND, 2, "fp32")
+    fw = frameworks.InpaintCFG(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
+    smp = samplers.DdimSampler(fw)
+    x_T = C.seeded_randn(411, 2, 4, 128, 128)
+    assert abs(float(x_T.double().sum()) - float(g["x_checksum"])) < 1e-6
+    cls = torch.from_numpy(g["classes"]).cuda()
+    errs = {}
+    for prec in CHAIN_MODES:
+        m.set_precision(prec)
+        torch.manual_seed(17)
+        res = smp.sample(2, noise=x_T.cuda(), classes=cls, steps=50, strength=3.0, verbose=False, y=y, mask=mask, mask_rgb=mask_rgb,
+                         replace_rgb=(0.1, color, mask_rgb), replace_depth=(0.2, depth, mask), constrain_depth=(0.5, convex),
+                         noise_fn=_cpu_noise_fn())
+        assert torch.isfinite(res.samples).all()
+        errs[prec] = dict(samples=C.rel_l2(res.samples.cpu(), g["samples"]), x0_first=C.rel_l2(res.pred_x_0[0].cpu(), g["x0_first"]),
+                          x0_mid=C.rel_l2(res.pred_x_0[25].cpu(), g["x0_mid"]), x0_last=C.rel_l2(res.pred_x_0[-1].cpu(), g["x0_last"]))
+    _chain_report("inpaint50_cfg3_mini128cond", errs)
+
+
+def test_superres_cfg3_chain_in_the_16bit_modes():
+    """BASELINE config 5's sampler setting (SuperResCFG strength 3.0 + DDIM) on the mini SR model, every precision mode against
+    the live reference's chain (tests/golden/mini_superres.npz, make_golden_sr.py)."""
+    from ivid_amd.diffusion import frameworks
+    from ivid_amd.inference.superres import super_resolve
+    g = C.load_golden("mini_superres")
+    m, _ = build(C.MINI_SR, 7, "fp32")
+    fw = frameworks.SuperResCFG(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    low, cls2 = torch.from_numpy(g["low"]).cuda(), torch.from_numpy(g["classes"]).cuda()
+    errs = {}
+    for prec in CHAIN_MODES:
+        m.set_precision(prec)
+        torch.manual_seed(3)
+        ours = super_resolve(fw, low, classes=cls2, steps=4, strength=3.0, noise_fn=_cpu_noise_fn()).cpu()
+        eps = fw.model_inference(torch.from_numpy(g["x"]).cuda(), torch.full((2,), 500).cuda(), low, classes=cls2, strength=3.0).cpu()
+        errs[prec] = dict(samples=C.rel_l2(ours, g["samples"]), framework_eps_cfg3=C.rel_l2(eps, g["eps"]))
+    _chain_report("superres4_cfg3_minisr", errs)
+
+
 def test_cfg_strength_zero_and_negative_follow_the_reference_formula():
     """classifier_free_guidance.py:39-42: (1 + s) * eps_c - (s * eps_u if s > 0 else 0) -- for s <= 0 there is no second
     forward, but the conditional branch is still scaled by (1 + s)."""
