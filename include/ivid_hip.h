@@ -71,6 +71,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_STEM_IM2COL_SPLIT 19 /* ivid_stem_im2col_split */
 #define IVID_OP_CONV3X3_GN_SKIP_S 20 /* ivid_conv3x3_gn_skip_s */
 #define IVID_OP_F32_TO_HILO 21    /* ivid_f32_to_hilo */
+#define IVID_OP_GN_APPLY_P 22     /* ivid_gn_apply_p */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -228,6 +229,15 @@ int ivid_gn_apply(int dtype, const void* src0, int C0, const void* src1, int C1,
 /* Same with the lo planes of the two sources (see ivid_conv2d_c; NULL = none): x = hi + lo.  `out` is a plain tensor. */
 int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1,
                     const float* ab, void* out, int N, int H, int W, int resample, int act, void* stream);
+
+/* ivid_gn_apply_c with resample 2 that also writes the 2x2 average of the RAW sources (hi + lo read, summed in fp32):
+ * pool_hi [N,H/2,W/2,C0+C1] and, if pool_lo != NULL, the part its 16-bit rounding dropped.  That is `x_upd(x)` of a `down`
+ * ResBlock (adm.py:205-208: `x = self.x_upd(x)` feeds `self.skip_connection(x) + h`): the block's second convolution then adds
+ * a same-size residual (res_mode 1) instead of averaging four full-size pixels per output in its epilogue (res_mode 3).
+ * pool_hi == NULL: identical to ivid_gn_apply_c.  16-bit dtypes. */
+int ivid_gn_apply_p(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1,
+                    const float* ab, void* out, void* pool_hi, void* pool_lo, int N, int H, int W, int resample, int act,
+                    void* stream);
 
 /* ---- QKVAttention (adm.py:233-253), legacy per-head [q|k|v] channel interleave ----
  * qkv: NHWC [N,T,3*C] with channel = head*192 + {0..63 q, 64..127 k, 128..191 v}; out: [N,T,C], channel = head*64+d.

@@ -162,12 +162,16 @@ __global__ __launch_bounds__(FIN_NT) void gn_finalize_kernel(const float* __rest
 
 // resample: 0 same, 1 nearest x2 up (output 2H x 2W), 2 avg-pool x2 of activated values (output H/2 x W/2)
 // LO: the sources may carry lo planes (compensated 16-bit storage, see conv_igemm.hip ConvArgs): x = hi + lo
-template <typename T, int ACT, bool LO = false>
+// POOL (resample 2 only): the 2x2 average of the RAW inputs is written as well (pool_hi, and pool_lo = what the 16-bit rounding of
+// pool_hi dropped, if given) -- the residual `x_upd(x)` of a `down` ResBlock (adm.py:205-208), so that the block's second
+// convolution adds a same-size residual instead of averaging four pixels of the full-size tensor per output in its epilogue.
+template <typename T, int ACT, bool LO = false, bool POOL = false>
 __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict__ src0, int C0,
                                                          const char* __restrict__ src1, int C1,
                                                          const float* __restrict__ ab, char* __restrict__ out, int H,
                                                          int W, int resample, int ppc, const char* __restrict__ lo0 = nullptr,
-                                                         const char* __restrict__ lo1 = nullptr) {
+                                                         const char* __restrict__ lo1 = nullptr, char* __restrict__ pool_hi = nullptr,
+                                                         char* __restrict__ pool_lo = nullptr) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
   const int C = C0 + C1, CV = C / VE, CV0 = C0 / VE;
@@ -210,8 +214,13 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
       float r[VE];
       if (resample == 2) {
         const int yo = p / Wo, xo = p - yo * Wo;
+        float raw[POOL ? VE : 1];
 #pragma unroll
         for (int e = 0; e < VE; ++e) r[e] = 0.f;
+        if constexpr (POOL) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) raw[e] = 0.f;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const size_t sp = ((size_t)n * H + 2 * yo + (d >> 1)) * W + 2 * xo + (d & 1);
@@ -221,10 +230,25 @@ __global__ __launch_bounds__(GN_NT) void gn_apply_kernel(const char* __restrict_
           for (int e = 0; e < VE; ++e) {
             const float y = f[e] * a[e] + b[e];
             r[e] += ACT ? silu_f(y) : y;
+            if constexpr (POOL) raw[e] += f[e];      // same order as the convolution epilogue's res_mode 3
           }
         }
 #pragma unroll
         for (int e = 0; e < VE; ++e) r[e] *= 0.25f;
+        if constexpr (POOL) {
+          const size_t po = (((size_t)n * HWo + p) * C + (size_t)cv * VE) * sizeof(T);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) raw[e] *= 0.25f;
+          const vec_t ph = f32_to_vec<T>(raw);
+          *(vec_t*)(pool_hi + po) = ph;
+          if (pool_lo) {
+            float g[VE];
+            vec_to_f32<T>(ph, g);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) g[e] = raw[e] - g[e];
+            *(vec_t*)(pool_lo + po) = f32_to_vec<T>(g);
+          }
+        }
       } else {
         size_t sp;
         if (resample == 1) {
@@ -307,7 +331,18 @@ extern "C" int ivid_gn_apply(int dtype, const void* src0, int C0, const void* sr
 // with optional lo planes of the two sources (compensated 16-bit storage, precision mode fp16c); the output is a plain tensor
 extern "C" int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
                                int C1, const float* ab, void* out, int N, int H, int W, int resample, int act, void* stream) {
+  return ivid_gn_apply_p(dtype, src0, src0_lo, C0, src1, src1_lo, C1, ab, out, nullptr, nullptr, N, H, W, resample, act, stream);
+}
+
+// ... and, for resample 2 (2x2 average pool), the pooled RAW input as a second output (pool_hi [+ pool_lo]): the residual of a
+// `down` ResBlock; 16-bit dtypes only
+extern "C" int ivid_gn_apply_p(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                               int C1, const float* ab, void* out, void* pool_hi, void* pool_lo, int N, int H, int W, int resample,
+                               int act, void* stream) {
   if (int e = check_channels(dtype, C0, C1, src1)) return e;
+  if (pool_lo && !pool_hi) return ivid_set_error("gn_apply: pool_lo without pool_hi", hipSuccess);
+  if (pool_hi && (resample != 2 || ivid_esz(dtype) != 2))
+    return ivid_set_error("gn_apply: the pooled raw output exists for resample 2 in the 16-bit dtypes", hipSuccess);
   const bool lo = src0_lo || src1_lo;
   if (lo && ivid_esz(dtype) != 2) return ivid_set_error("gn_apply: lo planes need a 16-bit dtype", hipSuccess);
   if (resample < 0 || resample > 2) return ivid_set_error("gn_apply: bad resample", hipSuccess);
@@ -324,7 +359,14 @@ extern "C" int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo,
 #define LAUNCH_LO(T, A)                                                                                                 \
   hipLaunchKernelGGL((gn_apply_kernel<T, A, true>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
                      C1, ab, (char*)out, H, W, resample, ppc, (const char*)src0_lo, (const char*)src1_lo)
-  if (lo) {
+#define LAUNCH_POOL(T, A)                                                                                                     \
+  hipLaunchKernelGGL((gn_apply_kernel<T, A, true, true>), grid, dim3(GN_NT), 0, s, (const char*)src0, C0, (const char*)src1, \
+                     C1, ab, (char*)out, H, W, resample, ppc, (const char*)src0_lo, (const char*)src1_lo, (char*)pool_hi,    \
+                     (char*)pool_lo)
+  if (pool_hi) {
+    if (dtype == IVID_F16) { if (act) LAUNCH_POOL(_Float16, 1); else LAUNCH_POOL(_Float16, 0); }
+    else { if (act) LAUNCH_POOL(__bf16, 1); else LAUNCH_POOL(__bf16, 0); }
+  } else if (lo) {
     if (dtype == IVID_F16) { if (act) LAUNCH_LO(_Float16, 1); else LAUNCH_LO(_Float16, 0); }
     else { if (act) LAUNCH_LO(__bf16, 1); else LAUNCH_LO(__bf16, 0); }
   } else if (dtype == IVID_F32 || dtype == IVID_BF16X3) {
@@ -336,5 +378,6 @@ extern "C" int ivid_gn_apply_c(int dtype, const void* src0, const void* src0_lo,
   }
 #undef LAUNCH
 #undef LAUNCH_LO
+#undef LAUNCH_POOL
   return ivid_check_launch("gn_apply");
 }

@@ -224,6 +224,7 @@ class UNetPlan:
         # stacked CFG forward: what both halves of the batch have in common (everything in front of the first FiLM) is
         # computed once and duplicated
         self.share_cfg = os.environ.get("IVID_NO_CFG_SHARE", "0") != "1"
+        self.pool_res = os.environ.get("IVID_NO_POOL_RES", "0") != "1"       # `down` blocks: pooled residual from the gn_apply pass
         self._first_res_done = False
         self._sum_bias = {}
         self._tile_1x1 = int(os.environ.get("IVID_TILE_1X1", "0"))
@@ -374,16 +375,21 @@ class UNetPlan:
             self.arena.put(partial)
         return ab
 
-    def _gn(self, x0: _Act, x1, gname, film_off, resample, act, use_lo=True):
+    def _gn(self, x0: _Act, x1, gname, film_off, resample, act, use_lo=True, pool=None):
         """GroupNorm(+FiLM)(+SiLU)(+resample) of cat(x0,x1) materialised as a new activation (unfused path).  use_lo=False: read
-        the hi planes alone even where lo planes exist."""
+        the hi planes alone even where lo planes exist.  pool: an activation that receives the 2x2 average of the RAW input
+        (resample 2: the residual of a `down` ResBlock, adm.py:205-208)."""
         n, side = x0.n, x0.side
         c0, c1 = x0.c, (x1.c if x1 is not None else 0)
         ab = self._gn_coeffs(x0, x1, gname, film_off)
         so = {0: side, 1: side * 2, 2: side // 2}[resample]
         y = self._new(n, so, c0 + c1)
         lo0, lo1 = (x0.lo_ptr, (x1.lo_ptr if x1 is not None else None)) if use_lo else (None, None)
-        if lo0 is not None or lo1 is not None:
+        if pool is not None:
+            assert resample == 2 and self.esz == 2
+            self._rec("ivid_gn_apply_p", self.dtype, x0.ptr, lo0, c0, x1.ptr if x1 is not None else None, lo1, c1,
+                      ab.data_ptr(), y.ptr, pool.ptr, pool.lo_ptr, n, side, side, resample, act)
+        elif lo0 is not None or lo1 is not None:
             self._rec("ivid_gn_apply_c", self.dtype, x0.ptr, lo0, c0, x1.ptr if x1 is not None else None, lo1, c1,
                       ab.data_ptr(), y.ptr, n, side, side, resample, act)
         else:
@@ -451,6 +457,7 @@ class UNetPlan:
         # fp16cx: h1 (between the block's two convolutions) carries a lo plane too: out_layers' GroupNorm then
         # sees the unrounded in_layers result (not behind the phase-form up-convolution, whose epilogue scatters single planes)
         h1 = self._new(n, so, op.cout, stats=True, trunk=self.comp_in and not up4)
+        xpool = None
         if (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0
                 and op.cout > 32):
             # activated tensor at the SOURCE size (a quarter of the bytes of the upsampled one), then the phase convolution
@@ -487,7 +494,11 @@ class UNetPlan:
             self._conv3_gn(x, skip, ab1, op.mode == "up", op.prefix + ".in_layers.2", h1, None, 0)
             self.arena.put(ab1)
         else:
-            act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1)
+            # `down` block in a 16-bit mode: the same pass also emits x_upd(x) = the 2x2 average of the raw input, the residual of
+            # the block's second convolution (a same-size residual instead of four full-size pixels per output in its epilogue)
+            if op.mode == "down" and skip is None and not op.has_skip_conv and self.esz == 2 and self.pool_res:
+                xpool = self._new(n, so, op.cin, trunk=True)
+            act1 = self._gn(x, skip, op.prefix + ".in_layers.0", None, resample, 1, pool=xpool)
             self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
                        op.cout, 9, out_act=h1, out_lo=h1.lo_ptr)
             self._free(act1)
@@ -531,8 +542,11 @@ class UNetPlan:
             res_ptr, res_lo, res_mode = r.ptr, r.lo_ptr, 1
         else:
             assert skip is None
-            r = None
-            res_ptr, res_lo, res_mode = x.ptr, x.lo_ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
+            r = xpool            # freed with the skip-conv temporary's code path below
+            if xpool is not None:
+                res_ptr, res_lo, res_mode = xpool.ptr, xpool.lo_ptr, 1
+            else:
+                res_ptr, res_lo, res_mode = x.ptr, x.lo_ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
         if fused2:
             self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode, res_lo=res_lo)
             self.arena.put(ab2)

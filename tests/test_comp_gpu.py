@@ -391,3 +391,34 @@ def test_f32_to_hilo_planes(dtype):
     assert common.rel_l2(hi.float() + lo.float(), x) < (1.5e-5 if dtype == 1 else 1e-6)
     assert L.load().ivid_f32_to_hilo(0, L.ptr(x), L.ptr(hi), L.ptr(lo), x.numel(), G.stream()) != 0
     assert L.load().ivid_f32_to_hilo(dtype, L.ptr(x), L.ptr(hi), L.ptr(lo), 12, G.stream()) != 0
+
+
+@pytest.mark.parametrize("dtype", DT16)
+@pytest.mark.parametrize("with_lo", [True, False])
+def test_gn_apply_p_also_emits_the_pooled_raw_input(dtype, with_lo):
+    """ivid_gn_apply_p: out = avg_pool(silu(x*a+b)) exactly as ivid_gn_apply_c, plus x_upd(x) = avg_pool(x) (adm.py:205-208) as hi
+    [+ lo] planes -- the residual of a `down` ResBlock."""
+    L = G.lib()
+    N, H, W, C0 = 2, 16, 32, 128
+    x0 = common.seeded_randn(31, N, C0, H, W) * 3
+    a = 0.5 + 0.5 * torch.rand(N, C0, generator=torch.Generator().manual_seed(7))
+    b = 0.3 * common.seeded_randn(32, N, C0)
+    if with_lo:
+        h0, l0, v0 = planes(x0, dtype)
+    else:
+        h0, l0, v0 = G.to_nhwc(x0, dtype), None, G.rounded(x0, dtype)
+    t = G.tdt(dtype)
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    out = torch.full((N, H // 2, W // 2, C0), float("nan"), device="cuda", dtype=t)
+    ph, pl, out_c = torch.full_like(out, float("nan")), torch.full_like(out, float("nan")), torch.full_like(out, float("nan"))
+    L.call("ivid_gn_apply_p", dtype, L.ptr(h0), L.ptr(l0), C0, None, None, 0, L.ptr(ab), L.ptr(out), L.ptr(ph), L.ptr(pl) if with_lo else None,
+           N, H, W, 2, 1, G.stream())
+    L.call("ivid_gn_apply_c", dtype, L.ptr(h0), L.ptr(l0), C0, None, None, 0, L.ptr(ab), L.ptr(out_c), N, H, W, 2, 1, G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_c)
+    want = F.avg_pool2d(v0.double(), 2).float()
+    if with_lo:
+        assert common.rel_l2(joined(ph, pl), want) < PAIR_BAR[dtype]
+    assert torch.equal(ph.cpu(), G.to_nhwc(want, dtype).cpu()) or common.rel_l2(G.from_nhwc(ph), want) < (4e-3 if dtype == 1 else 5e-4)
+    # refused where it does not exist
+    assert L.load().ivid_gn_apply_p(dtype, L.ptr(h0), None, C0, None, None, 0, L.ptr(ab), L.ptr(out), L.ptr(ph), None, N, H, W, 0, 1, G.stream()) != 0
