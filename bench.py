@@ -180,6 +180,9 @@ def parse_args(argv=None):
                          "depth-warp in the loop, bs 32: samples/s and the share of the time spent outside the UNet.  c4: the same "
                          "on the `3x9` viewset (27 views per sample, 26 warped / inpainted).  c5: c4 + the 128->256 super-resolution "
                          "chain on every view (SR model, 50-step DDIM, CFG).  One batch of 32 samples per rank")
+    ap.add_argument("--sr-precision", default="bf16", choices=sorted(DTYPE_CODE),
+                    help="precision mode of the super-resolution model in --config c5: BASELINE.json names bf16 for that chain "
+                         "(configs[4]: '... super-resolution chain (128->256) stacked on 3x9 viewset, bf16, 8xMI355X')")
     ap.add_argument("--c3-steps-uncond", type=int, default=1000)
     ap.add_argument("--c3-steps-cond", type=int, default=50)
     ap.add_argument("--launcher-dry-run", action="store_true",
@@ -317,6 +320,10 @@ def canonical_launch(name, args):
         plane = n * h * w * cout * ESZ[dt]
         extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
         return "ivid_conv2d", tuple(a for i, a in enumerate(args) if i not in (8, 10)), float(extra)
+    if name == "ivid_conv3x3_gn_o16":      # bf16x3 island layer that writes the fp16 twin of its result (+ fp32 when out != NULL)
+        (s0, c0, s1, c1, ab, w, b, o, _h, _l, r, rm, n, h, ww, cout, st) = args
+        twin = float(n * h * ww * cout * 4)
+        return "ivid_conv3x3_gn", (3, s0, c0, s1, c1, ab, 0, w, b, o, r, rm, n, h, ww, cout, st), twin if o is not None else 0.0
     if name == "ivid_conv3x3_gn_skip_s":   # the split skip phase re-reads the skip sources' lo planes and the lo weights
         sk_lo = args[16] * args[17] * args[18] * (args[22] + args[24]) * ESZ[args[0]]
         nm, a2, extra = canonical_launch("ivid_conv3x3_gn_skip_c", args[:26])
@@ -674,10 +681,10 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
     bs = 32 if a.batch == 64 else a.batch
     su, sc = a.c3_steps_uncond, a.c3_steps_cond
 
-    def model(args, seed):
+    def model(args, seed, precision=None):
         sd = C.synth_weights(args, seed) if rank == 0 else None
         sd = parallel.broadcast_state_dict(C.schema_for(args), sd, device=dev)
-        m = AdmUnet2d(**args, precision=a.precision)
+        m = AdmUnet2d(**args, precision=precision or a.precision)
         m.load_state_dict(sd, strict=True)
         return m.to(dev).eval()
     cargs = dict(C.LARGE128, in_channels=10)          # rgbd_imagenet_adm_128_large_cond.json
@@ -691,7 +698,7 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
     fsr = None
     if a.config == "c5":      # rgbd_imagenet_adm_256_128_small_sr.json: SuperResCFG on every generated view (BASELINE config 5)
         from ivid_amd.inference.superres import super_resolve
-        msr = model(C.SR256, 6)
+        msr = model(C.SR256, 6, a.sr_precision)     # BASELINE config 5 states bf16 for the SR chain
         fsr = frameworks.SuperResCFG(msr, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
 
     sr_seconds = [0.0]
@@ -792,6 +799,8 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
     if getattr(a, "precision_selection", None):
         out["precision_selection"] = a.precision_selection
     if fsr is not None:
+        out["sr_precision_mode"] = a.sr_precision
+        out["sr_precision_note"] = "BASELINE.json configs[4] names bf16 for the super-resolution chain; the 128^2 models run in `precision_mode`"
         out["sr_seconds_per_batch"] = round(sr_seconds[0], 3)
         out["sr_views_per_s"] = round(bs * nviews / sr_seconds[0], 2)
         out["config4_samples_per_s_same_run"] = round(bs * world / (dt - sr_seconds[0]), 4)     # the run minus its SR stage = config 4

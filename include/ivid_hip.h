@@ -72,6 +72,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_CONV3X3_GN_SKIP_S 20 /* ivid_conv3x3_gn_skip_s */
 #define IVID_OP_F32_TO_HILO 21    /* ivid_f32_to_hilo */
 #define IVID_OP_GN_APPLY_P 22     /* ivid_gn_apply_p */
+#define IVID_OP_CONV3X3_GN_O16 23 /* ivid_conv3x3_gn_o16 */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -184,6 +185,15 @@ int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* src0_lo, int
                            const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats, const void* skip0,
                            int skipC0, const void* skip1, int skipC1, const void* skip_weight, const void* skip0_lo,
                            const void* skip1_lo, const void* skip_weight_lo, void* stream);
+
+/* ivid_conv3x3_gn for IVID_BF16X3 (fp32 storage, split-bf16 MFMA; no upsample, no skip phase) whose result leaves as two
+ * fp16 planes out16_hi = fp16(v), out16_lo = fp16(v - hi) -- the compensated storage form of the 16-bit modes -- in addition
+ * to (out != NULL) or instead of (out == NULL) the fp32 tensor: the last layers of the fp16s mode's split-precision island
+ * (stem + first encoder level, adm.py:373-402) hand their tensors to the 16-bit part of the network without a conversion
+ * pass.  GroupNorm partials as ivid_conv3x3_gn. */
+int ivid_conv3x3_gn_o16(const void* src0, int C0, const void* src1, int C1, const float* ab, const void* weight, const float* bias,
+                        void* out, void* out16_hi, void* out16_lo, const void* res, int res_mode, int N, int H, int W, int Cout,
+                        float* stats, void* stream);
 
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].

@@ -66,6 +66,10 @@ struct FusedArgs {
   const char* sk0_lo;
   const char* sk1_lo;
   const char* skw_lo;
+  // O16 instantiation (bf16x3 island of the fp16s mode): the result ALSO (out != NULL) or ONLY (out == NULL) leaves as two
+  // fp16 planes hi + lo -- the compensated storage form the 16-bit part of the network reads
+  char* out16_hi;
+  char* out16_lo;
 #ifdef IVID_DEV_TIMELINE
   unsigned long long* dbg;             // [blocks][8] phase time stamps (scripts/dev/fused_timeline.py)
 #endif
@@ -98,7 +102,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 // One output tile (8 x 32 pixels x 256 output channels) of the launch: the whole kernel body.  `tile` is the logical tile id.
 // LO: output / residual lo planes in the epilogue.  LOIN: the halo transform reads lo planes of the inputs as well.
 // SKS: the 1x1 skip phase runs in split precision (three MFMA passes per chunk).
-template <typename T, bool LO, bool LOIN, bool SKS>
+template <typename T, bool LO, bool LOIN, bool SKS, bool O16>
 __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
@@ -764,7 +768,19 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
           for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
         }
         const vec_t ov = f32_to_vec<T>(v);
-        *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+        if constexpr (O16) {   // fp32 storage (VE = 4): the fp16 twin of the value, 8-byte stores
+          f16x4 th, tl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            th[e] = (_Float16)v[e];
+            tl[e] = (_Float16)(v[e] - (float)th[e]);
+          }
+          *(f16x4*)(p.out16_hi + (m * Cout + n) * 2) = th;
+          *(f16x4*)(p.out16_lo + (m * Cout + n) * 2) = tl;
+          if (p.out) *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+        } else {
+          *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+        }
         float sv[VE];
         vec_to_f32<T>(ov, sv);
         if constexpr (LO) {
@@ -821,13 +837,14 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
 // range walked side by side -- is bit-identical and 1.5-3 % slower on every layer (128^2 256->256: 1011 vs 1027 TF/s, 512->256:
 // 1199 vs 1218): the barrier between tiles and ~100 scalar spills of the hoisted launch constants cost more than the
 // workgroup dispatch it saves.)
-template <typename T, bool LO = false, bool LOIN = false, bool SKS = false>
+template <typename T, bool LO = false, bool LOIN = false, bool SKS = false, bool O16 = false>
 __global__ __launch_bounds__(NT) void conv3x3_fused_kernel(const FusedArgs p) {
-  fused_tile<T, LO, LOIN, SKS>(p, xcd_remap(blockIdx.x, p.ntiles_total));
+  fused_tile<T, LO, LOIN, SKS, O16>(p, xcd_remap(blockIdx.x, p.ntiles_total));
 }
 
-template <typename T, bool LO = false, bool LOIN = false, bool SKS = false> int launch_fused(const FusedArgs& a, hipStream_t stream) {
-  auto kern = conv3x3_fused_kernel<T, LO, LOIN, SKS>;
+template <typename T, bool LO = false, bool LOIN = false, bool SKS = false, bool O16 = false>
+int launch_fused(const FusedArgs& a, hipStream_t stream) {
+  auto kern = conv3x3_fused_kernel<T, LO, LOIN, SKS, O16>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -843,12 +860,42 @@ template <typename T, bool LO = false, bool LOIN = false, bool SKS = false> int 
 // with optional lo planes of the output and the residual source (compensated 16-bit storage, precision mode fp16c) and,
 // optionally, the 1x1 skip phase in split precision (skip_weight_lo != NULL: lo planes of the skip sources + the lo part of
 // the skip weights, precision mode fp16s)
+static int fused_any(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                     int C1, const float* ab, int up,
+                     const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                     const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
+                     const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
+                     const void* skip0_lo, const void* skip1_lo, const void* skip_weight_lo, void* out16_hi, void* out16_lo,
+                     void* stream);
+
 extern "C" int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
                                       int C1, const float* ab, int up,
                                       const void* weight, const float* bias, void* out, void* out_lo, const void* res,
                                       const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
                                       const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
                                       const void* skip0_lo, const void* skip1_lo, const void* skip_weight_lo, void* stream) {
+  return fused_any(dtype, src0, src0_lo, C0, src1, src1_lo, C1, ab, up, weight, bias, out, out_lo, res, res_lo, res_mode, N, H, W, Cout,
+                   stats, skip0, skipC0, skip1, skipC1, skip_weight, skip0_lo, skip1_lo, skip_weight_lo, nullptr, nullptr, stream);
+}
+
+// IVID_BF16X3 only (fp32 storage in, split-bf16 MFMA): the result leaves as two fp16 planes hi + lo (out16_hi / out16_lo: the
+// compensated storage form of the 16-bit modes) in addition to (out != NULL) or instead of (out == NULL) the fp32 tensor --
+// the hand-over from the split-precision island of the fp16s mode to the 16-bit part of the network without a conversion pass.
+extern "C" int ivid_conv3x3_gn_o16(const void* src0, int C0, const void* src1, int C1, const float* ab, const void* weight,
+                                   const float* bias, void* out, void* out16_hi, void* out16_lo, const void* res, int res_mode, int N,
+                                   int H, int W, int Cout, float* stats, void* stream) {
+  if (!out16_hi || !out16_lo) return ivid_set_error("conv3x3_gn_o16: both fp16 planes are required", hipSuccess);
+  return fused_any(IVID_BF16X3, src0, nullptr, C0, src1, nullptr, C1, ab, 0, weight, bias, out, nullptr, res, nullptr, res_mode, N, H, W,
+                   Cout, stats, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, out16_hi, out16_lo, stream);
+}
+
+static int fused_any(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                     int C1, const float* ab, int up,
+                     const void* weight, const float* bias, void* out, void* out_lo, const void* res,
+                     const void* res_lo, int res_mode, int N, int H, int W, int Cout, float* stats,
+                     const void* skip0, int skipC0, const void* skip1, int skipC1, const void* skip_weight,
+                     const void* skip0_lo, const void* skip1_lo, const void* skip_weight_lo, void* out16_hi, void* out16_lo,
+                     void* stream) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv3x3_gn: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
@@ -897,9 +944,14 @@ extern "C" int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* s
   a.sk0 = (const char*)skip0; a.sk1 = (const char*)skip1; a.skw = (const char*)skip_weight; a.skC0 = skipC0; a.skC1 = skipC1;
   a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo; a.src0_lo = (const char*)src0_lo; a.src1_lo = (const char*)src1_lo;
   a.sk0_lo = (const char*)skip0_lo; a.sk1_lo = (const char*)skip1_lo; a.skw_lo = (const char*)skip_weight_lo;
+  a.out16_hi = (char*)out16_hi; a.out16_lo = (char*)out16_lo;
 #ifdef IVID_DEV_TIMELINE
   a.dbg = g_timeline;
 #endif
+  if (out16_hi) {
+    if (dtype != IVID_BF16X3 || narrow) return ivid_set_error("conv3x3_gn_o16: IVID_BF16X3, Cout > 128 only", hipSuccess);
+    return launch_fused<bf16x3_t, false, false, false, true>(a, (hipStream_t)stream);
+  }
   if (skip_weight_lo) {
     if (src0_lo || src1_lo) return launch_fused<_Float16, true, true, true>(a, (hipStream_t)stream);
     return launch_fused<_Float16, true, false, true>(a, (hipStream_t)stream);

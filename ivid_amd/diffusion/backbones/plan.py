@@ -195,11 +195,12 @@ class _Act:
     """An NHWC activation living in an arena buffer (+ optionally the GroupNorm partial statistics its producing
     convolution wrote: fp32 [n*side*side/32][c][2]).  `lo`: byte offset of the tensor's lo plane inside the same buffer
     (compensated 16-bit storage, include/ivid_hip.h ivid_conv2d_c) or None."""
-    __slots__ = ("buf", "n", "side", "c", "stats", "stats_blk", "lo")
+    __slots__ = ("buf", "n", "side", "c", "stats", "stats_blk", "lo", "twin")
 
     def __init__(self, buf, n, side, c, stats=None, lo=None):
         self.buf, self.n, self.side, self.c, self.stats, self.lo = buf, n, side, c, stats, lo
         self.stats_blk = 32   # pixels per statistics block, set by the producing launch
+        self.twin = None      # fp32 island tensor: its fp16 hi + lo form, written by the producer itself (ivid_conv3x3_gn_o16)
 
     @property
     def ptr(self):
@@ -224,6 +225,8 @@ class UNetPlan:
         # stacked CFG forward: what both halves of the batch have in common (everything in front of the first FiLM) is
         # computed once and duplicated
         self.share_cfg = os.environ.get("IVID_NO_CFG_SHARE", "0") != "1"
+        self.island_o16 = os.environ.get("IVID_NO_ISLAND_O16", "0") != "1"   # island blocks write their fp16 twin themselves
+        self._island_last = None
         self.pool_res = os.environ.get("IVID_NO_POOL_RES", "0") != "1"       # `down` blocks: pooled residual from the gn_apply pass
         self._first_res_done = False
         self._sum_bias = {}
@@ -285,11 +288,17 @@ class UNetPlan:
         """fp32 island tensor -> the compensated 16-bit storage form (hi + lo planes) of the main mode; the GroupNorm partials
         its producer wrote move over unchanged (they describe the same values up to 2^-22)."""
         assert self.dtype != _lib.BF16X3
-        y = self._new(a.n, a.side, a.c, trunk=True)
+        y = a.twin if a.twin is not None else self._new(a.n, a.side, a.c, trunk=True)
         y.stats, y.stats_blk, a.stats = a.stats, a.stats_blk, None
-        self._rec("ivid_f32_to_hilo", self.dtype, a.ptr, y.ptr, y.lo_ptr, a.n * a.side * a.side * a.c)
+        if a.twin is None:
+            self._rec("ivid_f32_to_hilo", self.dtype, a.ptr, y.ptr, y.lo_ptr, a.n * a.side * a.side * a.c)
         self._free(a)
         return y
+
+    def _new16(self, n, side, c):
+        """An activation in the MAIN mode's compensated 16-bit storage, whatever the current (island) mode is."""
+        nb = (n * side * side * c * 2 + 255) // 256 * 256
+        return _Act(self.arena.get(2 * nb), n, side, c, None, lo=nb)
 
     # ---- launch recording ----
     def _rec(self, name, *args):
@@ -547,7 +556,18 @@ class UNetPlan:
                 res_ptr, res_lo, res_mode = xpool.ptr, xpool.lo_ptr, 1
             else:
                 res_ptr, res_lo, res_mode = x.ptr, x.lo_ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
-        if fused2:
+        if fused2 and self.dtype == _lib.BF16X3 and self._main_mode[0] != _lib.BF16X3 and op.cout > 128 and self.island_o16:
+            # island of the fp16s mode: the block output also leaves as fp16 hi + lo planes (what everything outside the island
+            # reads); the LAST island block's fp32 form has no reader at all
+            out.twin = self._new16(n, so, op.cout)
+            out.stats_blk = 128
+            keep32 = op.prefix != self._island_last
+            self._rec("ivid_conv3x3_gn_o16", h1.ptr, h1.c, None, 0, ab2.data_ptr(), self.w[op.prefix + ".out_layers.3.weight"].data_ptr(),
+                      self.w[op.prefix + ".out_layers.3.bias"].data_ptr(), out.ptr if keep32 else None, out.twin.ptr, out.twin.lo_ptr,
+                      res_ptr, res_mode, n, so, so, op.cout, out.stats.data_ptr() if out.stats is not None else None)
+            self.arena.put(ab2)
+            self._free(h1)
+        elif fused2:
             self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", out, res_ptr, res_mode, res_lo=res_lo)
             self.arena.put(ab2)
             self._free(h1)
@@ -598,6 +618,8 @@ class UNetPlan:
         island = sorted(w.island)
         if island:
             self._set_island(True)
+            last = sp.stages[island[-1]].ops[-1]
+            self._island_last = last.prefix if isinstance(last, Res) else None
         xin = self._new(n, S, w.stem_k)
         self._rec("ivid_stem_im2col_split" if self.comp else "ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n,
                   sp.in_channels, S, S, w.stem_k, xin.ptr)

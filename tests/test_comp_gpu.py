@@ -422,3 +422,43 @@ def test_gn_apply_p_also_emits_the_pooled_raw_input(dtype, with_lo):
     assert torch.equal(ph.cpu(), G.to_nhwc(want, dtype).cpu()) or common.rel_l2(G.from_nhwc(ph), want) < (4e-3 if dtype == 1 else 5e-4)
     # refused where it does not exist
     assert L.load().ivid_gn_apply_p(dtype, L.ptr(h0), None, C0, None, None, 0, L.ptr(ab), L.ptr(out), L.ptr(ph), None, N, H, W, 0, 1, G.stream()) != 0
+
+
+@pytest.mark.parametrize("res_mode", [0, 1])
+def test_conv3x3_gn_o16_writes_the_fp16_twin_of_the_bf16x3_result(res_mode):
+    """ivid_conv3x3_gn_o16: the split-precision (IVID_BF16X3) fused convolution whose result leaves as fp16 hi + lo planes.  The fp32
+    output must be bit-identical to ivid_conv3x3_gn's, the planes must be exactly fp16(v) and fp16(v - hi) of it, with or without
+    the fp32 output, and the GroupNorm partials must not change."""
+    L = G.lib()
+    N, H, W, C0, Cout = 2, 16, 32, 64, 256
+    x = common.seeded_randn(41, N, C0, H, W) * 2
+    a = 0.5 + 0.5 * torch.rand(N, C0, generator=torch.Generator().manual_seed(9))
+    b = 0.3 * common.seeded_randn(42, N, C0)
+    w = common.seeded_randn(43, Cout, C0, 3, 3) / np.sqrt(C0 * 9)
+    bias = common.seeded_randn(44, Cout) * 0.1
+    res = common.seeded_randn(45, N, Cout, H, W) if res_mode else None
+    xd, rd = G.to_nhwc(x, 3), (G.to_nhwc(res, 3) if res is not None else None)
+    ab = torch.stack([a, b], -1).contiguous().cuda()
+    wp, bd = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), 3), bias.cuda()
+    ref32 = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    st0 = torch.full((N * H * W // 128, Cout, 2), float("nan"), device="cuda")
+    L.call("ivid_conv3x3_gn", 3, L.ptr(xd), C0, None, 0, L.ptr(ab), 0, L.ptr(wp), L.ptr(bd), L.ptr(ref32), L.ptr(rd), res_mode, N, H, W, Cout,
+           L.ptr(st0), G.stream())
+    for keep32 in (True, False):
+        out = torch.full_like(ref32, float("nan"))
+        hi = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.float16)
+        lo = torch.full_like(hi, float("nan"))
+        st = torch.full_like(st0, float("nan"))
+        L.call("ivid_conv3x3_gn_o16", L.ptr(xd), C0, None, 0, L.ptr(ab), L.ptr(wp), L.ptr(bd), L.ptr(out) if keep32 else None, L.ptr(hi), L.ptr(lo),
+               L.ptr(rd), res_mode, N, H, W, Cout, L.ptr(st), G.stream())
+        torch.cuda.synchronize()
+        if keep32:
+            assert torch.equal(out, ref32)
+        assert torch.equal(hi, ref32.half()) and torch.equal(lo, (ref32 - ref32.half().float()).half())
+        assert torch.equal(st, st0)
+    want = F.conv2d(F.silu(x.double() * a[:, :, None, None].double() + b[:, :, None, None].double()), w.double(), bias.double(), padding=1)
+    if res is not None:
+        want = want + res.double()
+    assert common.rel_l2(joined(hi, lo), want.float()) < 4e-5     # the bf16x3 bar: 16 operand bits
+    assert L.load().ivid_conv3x3_gn_o16(L.ptr(xd), C0, None, 0, L.ptr(ab), L.ptr(wp), L.ptr(bd), None, L.ptr(hi), None, None, 0, N, H, W, Cout,
+                                        None, G.stream()) != 0
