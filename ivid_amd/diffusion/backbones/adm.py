@@ -210,6 +210,9 @@ class AdmUnet2d(nn.Module):
         if classes is not None:
             assert classes.shape == (x.shape[0],), "classes must be a 1-D batch of labels"
             assert self.has_null_class or bool(torch.all(classes >= 0)), "this model does not have a null class"
+            # nn.Embedding raises IndexError for an out-of-range label (adm.py:549); the gather kernel would read past the table
+            if int(classes.max()) >= self.num_classes:
+                raise IndexError(f"class label {int(classes.max())} out of range for num_classes = {self.num_classes}")
         assert x.shape[1:] == (self.in_channels, self.image_size, self.image_size), \
             f"expected input [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
         if x.shape[0] == 0:   # empty batch: what the reference's torch ops return (no launch)
@@ -224,6 +227,8 @@ class AdmUnet2d(nn.Module):
         that stay valid until the next call.  Replaces the two sequential backbone calls of
         classifier_free_guidance.py:39-42 / inpaint_cfg.py:80-83."""
         assert self.num_classes is not None and classes is not None
+        if int(classes.max()) >= self.num_classes:
+            raise IndexError(f"class label {int(classes.max())} out of range for num_classes = {self.num_classes}")
         b = x.shape[0]
         out = self.plan(b, True).run(x.float().contiguous(), times, classes, self.use_graph)
         return out[:b], out[b:]

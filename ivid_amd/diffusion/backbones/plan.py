@@ -457,9 +457,9 @@ class UNetPlan:
         n = x.n
         resample = {"same": 0, "up": 1, "down": 2}[op.mode]
         so = op.res_out
-        # Cout > 128: the 8x32x256 fused kernel.  Cout <= 128 (the small / SR models' first levels): its 16x32x128 variant
-        # with 64-byte chunks (csrc/conv3x3_fused128.hip; not for bf16x3, which keeps gn_apply + igemm there)
-        narrow_ok = self.fuse_narrow and self.dtype != _lib.BF16X3 and so % 32 == 0
+        # Cout > 128: the 8x32x256 shape of the fused kernel.  Cout <= 128 (the small / SR models' first levels): its 16x32x128
+        # shape with 64-byte chunks (csrc/conv3x3_fused_body.h, FusedShape<false>)
+        narrow_ok = self.fuse_narrow and so % 32 == 0
         fused2 = self.fuse_conv and so % 32 == 0 and (op.cout > 128 or narrow_ok)   # out_layers conv: input at the output size
         fused = fused2 and op.mode != "down"                             # in_layers conv: not behind the 2x2 average pool
         up4 = (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0 and op.cout > 32)
@@ -522,8 +522,7 @@ class UNetPlan:
         if op.cout <= 128:
             kstep //= 2                                       # the 128-wide variant works on 64-byte chunks
         if (fused2 and op.has_skip_conv and self.fuse_skip and x.c % kstep == 0
-                and (skip is None or skip.c % kstep == 0)
-                and not (self.split_skip and op.cout <= 128)):   # the split skip phase exists in the 256-wide kernel only
+                and (skip is None or skip.c % kstep == 0)):
             # 1x1 skip_connection folded into the out_layers conv kernel as extra K-steps (no separate launch, no
             # residual round trip)
             assert op.mode == "same"
@@ -556,7 +555,7 @@ class UNetPlan:
                 res_ptr, res_lo, res_mode = xpool.ptr, xpool.lo_ptr, 1
             else:
                 res_ptr, res_lo, res_mode = x.ptr, x.lo_ptr, {"same": 1, "up": 2, "down": 3}[op.mode]
-        if fused2 and self.dtype == _lib.BF16X3 and self._main_mode[0] != _lib.BF16X3 and op.cout > 128 and self.island_o16:
+        if fused2 and self.dtype == _lib.BF16X3 and self._main_mode[0] != _lib.BF16X3 and self.island_o16:
             # island of the fp16s mode: the block output also leaves as fp16 hi + lo planes (what everything outside the island
             # reads); the LAST island block's fp32 form has no reader at all
             out.twin = self._new16(n, so, op.cout)

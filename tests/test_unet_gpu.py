@@ -681,3 +681,16 @@ def test_fp16_mode_against_the_references_own_fp16_torso(name, args, seed, batch
              reference_fp16_vs_its_fp32=r16_32)
     print("fp16 vs reference fp16", name, e16, e32, r16_32)
     assert e16 < 3e-3 and e32 < 1.3 * r16_32 + 2e-4, (e16, e32, r16_32)
+
+
+def test_out_of_range_class_label_raises_like_nn_embedding():
+    """adm.py:549 `self.label_emb(classes)`: nn.Embedding raises IndexError for a label >= num_classes; the HIP gather must not read
+    past the table instead."""
+    m, _ = build(C.MINI, 0, "fp32")
+    x = C.seeded_randn(1, 2, 4, 32, 32).cuda()
+    t = torch.tensor([5, 7]).cuda()
+    with pytest.raises(IndexError):
+        m(x, t, torch.tensor([3, 10]).cuda())
+    with pytest.raises(IndexError):
+        m.forward_cfg(x, t, torch.tensor([416, 1]).cuda())
+    assert torch.isfinite(m(x, t, torch.tensor([9, -1]).cuda())).all()
