@@ -878,6 +878,11 @@ def cpu_baseline(C, margs, has_cls, model_name, B, unit):
     what = "reference AdmUnet2d (/root/reference, fp32 torch CPU)" if kind == "reference" else "oracle UNet forward (fp32 torch CPU)"
     return {"value": round(s_fwd / B, 5), "unit": unit, "cores": ncores, "host_logical_cpus": os.cpu_count(),
             "cpus_available_to_this_process": avail, "kind": kind,
+            "kind_note": ("the reference's own AdmUnet2d" if kind == "reference" else
+                          "/root/reference does not exist on this box: the oracle (oracle/adm_oracle.py, pinned to the reference "
+                          "bit-for-bit by tests/golden) is timed instead"),
+            "cores_note": "torch's CPU convolutions stop scaling (and oversubscribe) far below the host's logical CPU count: "
+                          "threads = min(available, IVID_CPU_BASELINE_THREADS = 64)",
             "sample": "%s, %s model: %d timed forwards at bs %d in %.1f s = %.2f sample-fwd/s, scaled to bs-%d forwards"
                       % (what, model_name, nrep, bs, cdt, s_fwd, B),
             "sample_fwd_per_s": round(s_fwd, 3)}

@@ -91,7 +91,8 @@ class AdmUnet2d(nn.Module):
             precision = "fp16s" if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
-        self.max_plans = int(os.environ.get("IVID_MAX_PLANS", "3"))
+        self.max_plans = int(os.environ.get("IVID_MAX_PLANS", "16"))
+        self.max_plan_bytes = int(float(os.environ.get("IVID_MAX_PLAN_BYTES", str(96 << 30))))
         self.tile_cfg = int(os.environ.get("IVID_TILE_CFG", "0"))
 
         # ---- parameters: same names / shapes / init statistics as the reference ----
@@ -182,24 +183,29 @@ class AdmUnet2d(nn.Module):
         return self._packed
 
     def plan(self, batch, stacked=False):
-        """Launch plan (activation arena + hipGraph) for one (batch, stacked-CFG) shape.  At most `max_plans` are kept,
-        least recently used first out: a ragged last batch (e.g. 10 000 samples in batches of 32 leave one of 16) builds a
-        second arena, but a stream of distinct batch sizes cannot pile arenas up (each is GBs at bs 64)."""
+        """Launch plan (activation arena + hipGraph) for one (batch, stacked-CFG) shape.  Plans are kept least recently used first
+        out under a BYTE budget (IVID_MAX_PLAN_BYTES, default 96 GiB of the 288 GB HBM; at most IVID_MAX_PLANS = 16 plans): a
+        sampling job cycles through a handful of shapes -- config 4's batches of 32 + its ragged last batch, config 5's 27-view SR
+        batches -- whose arenas are GBs each at bs 64 but fit side by side, while a stream of distinct large batch sizes cannot
+        pile arenas up."""
         key = (batch, stacked)
         p = self._plans.pop(key, None)
         if p is None:
-            while len(self._plans) >= self.max_plans:
+            p = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
+            need = p.arena.total_bytes()
+            while self._plans and (len(self._plans) >= self.max_plans
+                                   or need + sum(q.arena.total_bytes() for q in self._plans.values()) > self.max_plan_bytes):
                 okey = next(iter(self._plans))
                 old = self._plans.pop(okey)                         # dict order = recency (re-inserted on every hit)
                 torch.cuda.synchronize(self.device)                 # its buffers may still be in flight
                 self._evictions = getattr(self, "_evictions", 0) + 1
-                if self._evictions in (1, 10, 100):                 # a caller cycling through > max_plans shapes thrashes: say so
+                if self._evictions in (1, 10, 100):                 # a caller cycling through more shapes than fit thrashes: say so
                     import warnings
                     warnings.warn(f"AdmUnet2d: launch plan for (batch, stacked) = {okey} evicted ({old.arena.total_bytes() >> 20} MiB "
                                   f"arena; {self._evictions} evictions so far) to make room for {key}; every miss rebuilds arena + "
-                                  f"hipGraph.  Raise IVID_MAX_PLANS (now {self.max_plans}) if the workload cycles through more shapes.")
+                                  f"hipGraph.  Raise IVID_MAX_PLAN_BYTES (now {self.max_plan_bytes >> 30} GiB) / IVID_MAX_PLANS (now "
+                                  f"{self.max_plans}) if the workload cycles through more shapes.")
                 del old
-            p = UNetPlan(self.spec, self._weights(), self.device, batch, stacked, self.tile_cfg)
         self._plans[key] = p
         return p
 

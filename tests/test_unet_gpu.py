@@ -694,3 +694,23 @@ def test_out_of_range_class_label_raises_like_nn_embedding():
     with pytest.raises(IndexError):
         m.forward_cfg(x, t, torch.tensor([416, 1]).cuda())
     assert torch.isfinite(m(x, t, torch.tensor([9, -1]).cuda())).all()
+
+
+def test_plan_cache_keeps_plans_under_a_byte_budget():
+    """AdmUnet2d.plan: launch plans are kept LRU under a byte budget, not a small count: a job that cycles through a handful of
+    shapes (config 4's ragged last batch, config 5's 27-view SR batches) must not rebuild arena + hipGraph on every change."""
+    import warnings
+    m, _ = build(C.MINI, 0, "fp16s")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # no eviction warning for six mini-size shapes
+        plans = [m.plan(b, st) for b in (1, 2, 3) for st in (False, True)]
+        assert all(m.plan(b, st) is p for p, (b, st) in zip(plans, [(b, st) for b in (1, 2, 3) for st in (False, True)]))
+    one = plans[0].arena.total_bytes()
+    m.max_plan_bytes = int(2.5 * max(p.arena.total_bytes() for p in plans))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.plan(4, True)
+    assert len(m._plans) <= 3 and sum(p.arena.total_bytes() for p in m._plans.values()) <= m.max_plan_bytes + one
+    assert any("evicted" in str(x.message) for x in w)
+    x = C.seeded_randn(1, 4, 4, 32, 32).cuda()
+    assert torch.isfinite(m.forward_cfg(x, torch.full((4,), 3).cuda(), torch.tensor([1, 2, 3, 4]).cuda())[0]).all()
