@@ -73,6 +73,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_F32_TO_HILO 21    /* ivid_f32_to_hilo */
 #define IVID_OP_GN_APPLY_P 22     /* ivid_gn_apply_p */
 #define IVID_OP_CONV3X3_GN_O16 23 /* ivid_conv3x3_gn_o16 */
+#define IVID_OP_GN_PARTIAL_C 24   /* ivid_gn_partial_c */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -217,6 +218,10 @@ int ivid_conv3x3_gn_out_c(int dtype, const void* src, const void* src_lo, int C,
 int ivid_gn_num_chunks(int HW);
 int ivid_gn_partial(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int HW, float* partial,
                     void* stream);
+/* Same with the lo planes of the sources (compensated 16-bit storage, NULL = none): the statistics describe hi + lo, exactly like
+ * the partials the convolution epilogues write for such a tensor. */
+int ivid_gn_partial_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo, int C1, int N,
+                      int HW, float* partial, void* stream);
 /* Step 2: fold statistics, affine and FiLM into one per-(n,c) scale/offset:
  *   y = x*a + b,  a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale) + shift
  *   film: fp32 rows [N][film_stride]; scale = film[n][film_off + c], shift = film[n][film_off + C + c]

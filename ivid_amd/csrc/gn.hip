@@ -22,10 +22,12 @@ constexpr int GN_NT = 256;
 
 __host__ __device__ inline int gn_ppc(int HW) { return HW >= 4096 ? 256 : 64; }
 
-template <typename T>
+template <typename T, bool LO = false>
 __global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restrict__ src0, int C0,
                                                            const char* __restrict__ src1, int C1, int HW, int ppc,
-                                                           int nchunks, float* __restrict__ partial) {
+                                                           int nchunks, float* __restrict__ partial,
+                                                           const char* __restrict__ lo0 = nullptr,
+                                                           const char* __restrict__ lo1 = nullptr) {
   typedef typename Elem<T>::vec vec_t;
   constexpr int VE = Elem<T>::VE;
   __shared__ float red[GN_NT * VE * 2];
@@ -43,12 +45,21 @@ __global__ __launch_bounds__(GN_NT) void gn_partial_kernel(const char* __restric
     if (p0 < PIF) {
       const bool second = cv >= CV0;
       const char* base = second ? src1 : src0;
+      const char* lob = LO ? (second ? lo1 : lo0) : nullptr;   // statistics of a tensor with a lo plane describe hi + lo
       const int Cs = second ? C1 : C0;
       const int cc = (second ? cv - CV0 : cv) * VE;
       for (int p = pbeg + p0; p < pend; p += PIF) {
         const vec_t v = *(const vec_t*)(base + (((size_t)n * HW + p) * Cs + cc) * sizeof(T));
         float f[VE];
         vec_to_f32<T>(v, f);
+        if constexpr (LO) {
+          if (lob) {
+            float l[VE];
+            vec_to_f32<T>(*(const vec_t*)(lob + (((size_t)n * HW + p) * Cs + cc) * sizeof(T)), l);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) f[e] += l[e];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           s[e] += f[e];
@@ -287,9 +298,26 @@ extern "C" int ivid_gn_num_chunks(int HW) {
 
 extern "C" int ivid_gn_partial(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int HW,
                                float* partial, void* stream) {
+  return ivid_gn_partial_c(dtype, src0, nullptr, C0, src1, nullptr, C1, N, HW, partial, stream);
+}
+
+// with the lo planes of the sources (compensated 16-bit storage): the statistics describe hi + lo, like the ones the
+// convolution epilogues write
+extern "C" int ivid_gn_partial_c(int dtype, const void* src0, const void* src0_lo, int C0, const void* src1, const void* src1_lo,
+                                 int C1, int N, int HW, float* partial, void* stream) {
   if (int e = check_channels(dtype, C0, C1, src1)) return e;
   const int ppc = gn_ppc(HW), nchunks = (HW + ppc - 1) / ppc;
   dim3 grid(nchunks, N);
+  if (src0_lo || src1_lo) {
+    if (ivid_esz(dtype) != 2) return ivid_set_error("gn_partial: lo planes need a 16-bit dtype", hipSuccess);
+    if (dtype == IVID_F16)
+      hipLaunchKernelGGL((gn_partial_kernel<_Float16, true>), grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
+                         (const char*)src1, C1, HW, ppc, nchunks, partial, (const char*)src0_lo, (const char*)src1_lo);
+    else
+      hipLaunchKernelGGL((gn_partial_kernel<__bf16, true>), grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
+                         (const char*)src1, C1, HW, ppc, nchunks, partial, (const char*)src0_lo, (const char*)src1_lo);
+    return ivid_check_launch("gn_partial");
+  }
   if (dtype == IVID_F32 || dtype == IVID_BF16X3)
     hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(GN_NT), 0, (hipStream_t)stream, (const char*)src0, C0,
                        (const char*)src1, C1, HW, ppc, nchunks, partial);

@@ -49,6 +49,8 @@ int run_op(const Op& o, void* s) {
       return ivid_conv3x3_gn_out(I(0), CP(1), I(2), CFP(3), CP(4), CFP(5), FP(6), I(7), I(8), I(9), I(10), s);
     case IVID_OP_GN_PARTIAL:
       return ivid_gn_partial(I(0), CP(1), I(2), CP(3), I(4), I(5), I(6), FP(7), s);
+    case IVID_OP_GN_PARTIAL_C:
+      return ivid_gn_partial_c(I(0), CP(1), CP(2), I(3), CP(4), CP(5), I(6), I(7), I(8), FP(9), s);
     case IVID_OP_GN_FINALIZE:
       return ivid_gn_finalize(CFP(0), I(1), I(2), I(3), I(4), I(5), F(6), CFP(7), CFP(8), CFP(9), I(10), I(11), FP(12), s);
     case IVID_OP_GN_FINALIZE2:

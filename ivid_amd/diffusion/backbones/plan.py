@@ -377,8 +377,13 @@ class UNetPlan:
         else:
             nch = self.lib.ivid_gn_num_chunks(hw)
             partial = self.arena.get(n * nch * c * 2 * 4)
-            self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, n, hw,
-                      partial.data_ptr())
+            lo0, lo1 = x0.lo_ptr, (x1.lo_ptr if x1 is not None else None)
+            if lo0 is not None or lo1 is not None:   # the consumers of a tensor with a lo plane normalise hi + lo
+                self._rec("ivid_gn_partial_c", self.dtype, x0.ptr, lo0, c0, x1.ptr if x1 is not None else None, lo1, c1, n, hw,
+                          partial.data_ptr())
+            else:
+                self._rec("ivid_gn_partial", self.dtype, x0.ptr, c0, x1.ptr if x1 is not None else None, c1, n, hw,
+                          partial.data_ptr())
             self._rec("ivid_gn_finalize", partial.data_ptr(), nch, n, c, hw, self.spec.num_groups, 1e-5, gw, gb, film,
                       self.spec.emb_total, fo, ab.data_ptr())
             self.arena.put(partial)

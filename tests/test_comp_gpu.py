@@ -462,3 +462,21 @@ def test_conv3x3_gn_o16_writes_the_fp16_twin_of_the_bf16x3_result(res_mode):
     assert common.rel_l2(joined(hi, lo), want.float()) < 4e-5     # the bf16x3 bar: 16 operand bits
     assert L.load().ivid_conv3x3_gn_o16(L.ptr(xd), C0, None, 0, L.ptr(ab), L.ptr(wp), L.ptr(bd), None, L.ptr(hi), None, None, 0, N, H, W, Cout,
                                         None, G.stream()) != 0
+
+
+@pytest.mark.parametrize("dtype", DT16)
+def test_gn_partial_c_sums_hi_plus_lo(dtype):
+    L = G.lib()
+    N, H, W, C0, C1 = 2, 16, 16, 64, 32
+    x0, x1 = common.seeded_randn(51, N, C0, H, W) * 3, common.seeded_randn(52, N, C1, H, W)
+    h0, l0, v0 = planes(x0, dtype)
+    d1 = G.to_nhwc(x1, dtype)
+    nch = L.load().ivid_gn_num_chunks(H * W)
+    part = torch.full((N, nch, C0 + C1, 2), float("nan"), device="cuda")
+    L.call("ivid_gn_partial_c", dtype, L.ptr(h0), L.ptr(l0), C0, L.ptr(d1), None, C1, N, H * W, L.ptr(part), G.stream())
+    torch.cuda.synchronize()
+    v = torch.cat([v0, G.rounded(x1, dtype)], 1).double()
+    got_s, got_q = part[..., 0].sum(1).cpu().double(), part[..., 1].sum(1).cpu().double()
+    assert float((got_s - v.sum((2, 3))).abs().max()) < 2e-3 and float((got_q / (v * v).sum((2, 3)) - 1).abs().max()) < 1e-5
+    hi_only = torch.cat([G.rounded(x0, dtype), G.rounded(x1, dtype)], 1).double()
+    assert float(((hi_only * hi_only).sum((2, 3))[:, :C0] / got_q[:, :C0] - 1).abs().max()) > 1e-5     # the lo plane is in the sums

@@ -431,7 +431,7 @@ def test_fp16c_keeps_the_trunk_as_hi_plus_lo_planes():
     assert fused(m3) and sum(1 for a in fused(m3) if a[2] is not None) >= len(fused(m3)) - 2
 
 
-@pytest.mark.parametrize("precision", ["fp16c", "fp16cx", "fp16"])
+@pytest.mark.parametrize("precision", ["fp16s", "fp16c", "fp16cx", "fp16"])
 def test_16bit_forward_is_bitwise_batch_invariant(precision):
     """The sharding invariant in the headline precision: a sample's output must not depend on the batch it is computed in (ranks
     get different batch sizes: ragged last batches, `seeds[rank::world]`).  Statistics blocks, summation orders and the hi / lo
@@ -595,11 +595,13 @@ def test_cfg_strength_zero_and_negative_follow_the_reference_formula():
     assert C.rel_l2(got, 2.5 * ec - 1.5 * eu) < 1e-4
 
 
-def test_full_size_properties_large_bf16_bs64():
+@pytest.mark.parametrize("precision", ["bf16", "fp16s"])
+def test_full_size_properties_large_bf16_bs64(precision):
     """BASELINE config 2 shape (large model, bs 64, stacked CFG = batch 128) where the CPU oracle is too slow:
     size-independent properties — finite outputs, row i of the batch equals the bs-1 forward of sample i
-    (no cross-sample leakage through tiles / GroupNorm / attention), the null-class half equals classes=None."""
-    m, sd = build(C.LARGE128, 4, "bf16")
+    (no cross-sample leakage through tiles / GroupNorm / attention; BIT-identical in the headline mode), the null-class half
+    equals classes=None."""
+    m, sd = build(C.LARGE128, 4, precision)
     B = 64
     x = C.seeded_randn(7, B, 4, 128, 128).cuda()
     t = torch.full((B,), 500, dtype=torch.long).cuda()
@@ -611,12 +613,14 @@ def test_full_size_properties_large_bf16_bs64():
         one_c, one_u = m.forward_cfg(x[i:i + 1], t[i:i + 1], cls[i:i + 1])
         assert C.rel_l2(ec[i:i + 1].cpu(), one_c.cpu()) < 2e-3, i   # bf16 tile-order differences only
         assert C.rel_l2(eu[i:i + 1].cpu(), one_u.cpu()) < 2e-3, i
+        if precision == "fp16s":                                     # the sharding invariant at full size
+            assert torch.equal(ec[i:i + 1], one_c) and torch.equal(eu[i:i + 1], one_u), i
     un = m(x[:2], t[:2], None)
     assert C.rel_l2(eu[:2].cpu(), un.cpu()) < 2e-3
     g = C.load_golden("large128_fwd")   # and one row is anchored to the reference itself
     xg = C.seeded_randn(104, 1, 4, 128, 128)
     e = m.forward_cfg(xg.cuda(), torch.full((1,), 999).cuda(), torch.tensor([7]).cuda())[0].cpu()
-    G.report("unet/large128_bs64_bf16", golden_row_rel_l2=C.rel_l2(e, g["eps"]))
+    G.report("unet/large128_bs64_" + precision, golden_row_rel_l2=C.rel_l2(e, g["eps"]))
 
 
 def test_samplers_accept_a_foreign_framework_with_the_reference_contract():
@@ -714,3 +718,20 @@ def test_plan_cache_keeps_plans_under_a_byte_budget():
     assert any("evicted" in str(x.message) for x in w)
     x = C.seeded_randn(1, 4, 4, 32, 32).cuda()
     assert torch.isfinite(m.forward_cfg(x, torch.full((4,), 3).cuda(), torch.tensor([1, 2, 3, 4]).cuda())[0]).all()
+
+
+@pytest.mark.parametrize("precision", ["fp16c", "fp16s"])
+def test_unfused_statistics_path_normalises_hi_plus_lo(precision, monkeypatch):
+    """IVID_NO_FUSED_STATS=1 (GroupNorm partials from a separate pass instead of the convolution epilogues): with compensated
+    storage that pass must read hi + lo (ivid_gn_partial_c) -- the consumers normalise hi + lo -- so the mode keeps its deviation
+    from the reference (the hi-only partials made the coefficients inconsistent on this path)."""
+    g, x, t, cls = fwd_inputs("mini_fwd", C.MINI, 0, 2)
+    errs = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("IVID_NO_FUSED_STATS", env)
+        m, _ = build(C.MINI, 0, precision)
+        errs[env] = C.rel_l2(m(x.cuda(), t.cuda(), cls.cuda()).cpu(), g["eps"])
+        names = [n for _, n, _ in m.plan(2, False).launches]
+        assert ("ivid_gn_partial_c" in names) == (env == "1")
+    G.report(f"unet/mini_fwd_unfused_stats/{precision}", fused=errs["0"], unfused=errs["1"])
+    assert errs["1"] < PARITY_BAR and errs["1"] < 1.25 * errs["0"] + 5e-5, errs
