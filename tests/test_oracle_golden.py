@@ -120,3 +120,43 @@ def test_oracle_chain_matches_the_references_own_sample_all():
                                          replace_rgb=(0.1, color, mask_rgb), replace_depth=(0.2, depth, mask), constrain_depth=(0.5, convex))
         prev.append(res["samples"])
         assert C.rel_l2(prev[j][0], g["samples"][j]) < 1e-3, (j, C.rel_l2(prev[j][0], g["samples"][j]))
+
+
+def test_oracle_reproduces_the_representative_forward_set_small_and_large_rows():
+    """tests/golden/*_fwd_set.npz (round 4, make_golden_fwd_set.py): the seeded recipe rebuilds the generator's inputs and the
+    oracle reproduces the live reference's outputs -- all 12 rows of the small set, the hardest and an easy row of the large one
+    on both guidance branches (the generator checked every one of the 36 on the spot: manifest.json, rel-L2 0.0)."""
+    import json
+    import os
+    man = json.load(open(os.path.join(C.GOLDEN, "manifest.json")))
+    assert man["large128_fwd_set"]["oracle_vs_reference"]["rel_l2_max"] == 0.0
+    assert man["small128_fwd_set"]["oracle_vs_reference"]["rel_l2_max"] == 0.0
+    for gname, args, seed, keep in (("small128_fwd_set", C.SMALL128, 3, None), ("large128_fwd_set", C.LARGE128, 4, ("smooth_t20", "layers_t999"))):
+        g = C.load_golden(gname)
+        sd = C.synth_weights(args, seed)
+        ins = C.fwd_set_inputs(args["in_channels"], args["image_size"])
+        assert len(ins) == 12 and len({k for k, *_ in ins}) == 12
+        for key, x, t, cls in ins:
+            assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
+            if keep is not None and key not in keep:
+                continue
+            tt = torch.tensor([t])
+            if args["num_classes"] is not None:
+                assert C.rel_l2(adm_oracle.unet_forward(sd, args, x, tt, torch.tensor([cls])), g[key + "_c"]) < 1e-5, key
+            assert C.rel_l2(adm_oracle.unet_forward(sd, args, x, tt, None), g[key + "_u"]) < 1e-5, key
+
+
+def test_teacher_forced_steps_golden_is_consistent_with_the_chain_golden():
+    """large128_ddim50_cfg_steps.npz records what the reference's framework saw at sample_once calls 1, 10, 25, 49 of the config-2
+    chain: the timesteps must be those of the 50-step DDIM schedule (ddim.py:157: t - 1 of (1000 - 20 k)) and the oracle's guided
+    eps on the recorded input of step 49 must reproduce the recorded answer."""
+    g = C.load_golden("large128_ddim50_cfg_steps")
+    for k in (1, 10, 25, 49):
+        assert int(g[f"t_step{k}"]) == 1000 - 20 * k - 1
+        assert g[f"x_step{k}"].shape == g[f"eps_step{k}"].shape == (2, 4, 128, 128)
+    sd = C.synth_weights(C.LARGE128, 4)
+    cls = torch.from_numpy(g["classes"])
+    x, t = torch.from_numpy(g["x_step49"])[:1], torch.tensor([int(g["t_step49"])])
+    um = lambda a, b, c: adm_oracle.unet_forward(sd, C.LARGE128, a, b, c)
+    eps = sampler_oracle.cfg_eps(um, x, t, cls[:1], 0.5)
+    assert C.rel_l2(eps, g["eps_step49"][:1]) < 1e-5
