@@ -73,62 +73,57 @@ def parity_checks(model_name, precisions, dev, C):
     """Deviation of every mode in `precisions` from the LIVE REFERENCE's fp32 outputs (tests/golden/, generated from
     /root/reference by tests/golden/make_golden*.py), measured now on this GPU.  Per mode:
       fwd_noise_t999     one forward on pure noise at t = 999 (the fixture of rounds 1-3), max over the guidance branches
-      fwd_set_max/...    max / argmax / min over the representative forward set (tests/common.fwd_set_inputs: q-sampled
-                         scenes at six timesteps, both guidance branches for the class-conditional model)
+      fwd_set_max/...    max / argmax / min over the representative forward set of the model (tests/common.FWD_SETS: q-sampled
+                         scenes at several timesteps, both guidance branches; large cfg, small, the 10-channel conditional model on
+                         InpaintCFG inputs, the 256^2 super-resolution model on SuperResCFG inputs)
       chain_samples/...  the model's own BASELINE chain (large: config 2 = 50-step DDIM + CFG 0.5, bs 2; small: config 1 =
                          10-step DDIM, bs 2): samples and first x0 estimate
       teacher_forced_eps_max   (large) guided eps on the reference chain's own inputs at steps 1, 10, 25, 49
-    Returns ({mode: {...}}, description) -- empty when the model has no committed reference outputs (sr256)."""
+    Returns ({mode: {...}}, description)."""
     import torch
     from ivid_amd.diffusion import frameworks, samplers
     from ivid_amd.diffusion.backbones import AdmUnet2d
-    spec = {"large": ("large128_fwd", "large128_fwd_set", C.LARGE128, 4), "small": ("small128_fwd", "small128_fwd_set", C.SMALL128, 3)}.get(model_name)
-    if spec is None or not precisions:
+    tag = {"large": "large128", "small": "small128", "largecond": "largecond128", "sr256": "sr256"}.get(model_name)
+    if tag is None or not precisions:
         return {}, None
-    gname, sname, gargs, seed = spec
-    g, gs = C.load_golden(gname), C.load_golden(sname)
+    gargs, seed, sname = C.FWD_SETS[tag][:3]
+    gname = {"large": "large128_fwd", "small": "small128_fwd"}.get(model_name)
+    g = C.load_golden(gname) if gname else None
     S, cin = gargs["image_size"], gargs["in_channels"]
     has_cls = gargs["num_classes"] is not None
     gm = AdmUnet2d(**gargs, precision=precisions[0])
     gm.load_state_dict(C.synth_weights(gargs, seed), strict=True)
     gm = gm.to(dev).eval()
-    xg = C.seeded_randn(100 + seed, 1, cin, S, S).to(dev)
-    tg = torch.full((1,), int(g["t"]), dtype=torch.long, device=dev)
-    ins = C.fwd_set_inputs(cin, S)
-    xs = torch.cat([i[1] for i in ins]).to(dev)
-    ts = torch.tensor([i[2] for i in ins], device=dev)
-    cs = torch.tensor([i[3] for i in ins], device=dev) if has_cls else None
+    gc = gst = fw = None
     if model_name == "large":
         gc, gst = C.load_golden("large128_ddim50_cfg"), C.load_golden("large128_ddim50_cfg_steps")
         x_T, ccls = C.seeded_randn(2024, 2, 4, S, S).to(dev), torch.from_numpy(gc["classes"]).to(dev)
         steps, strength = int(gc["steps"]), float(gc["strength"])
         fw = frameworks.ClassifierFreeGuidance(gm, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
-    else:
-        gc, gst = C.load_golden("small128_ddim10"), None
+    elif model_name == "small":
+        gc = C.load_golden("small128_ddim10")
         x_T, ccls, steps, strength = C.seeded_randn(123, 2, 4, S, S).to(dev), None, 10, None
         fw = frameworks.GaussianDiffusion(gm, timesteps=1000, beta_schedule="linear")
     out = {}
     for prec in precisions:
         gm.set_precision(prec)
         r = {}
-        if has_cls:
-            ec, eu = gm.forward_cfg(xg, tg, torch.from_numpy(g["classes"]).to(dev))
-            r["fwd_noise_t999"] = max(C.rel_l2(ec.cpu(), g["eps"]), C.rel_l2(eu.cpu(), g["eps_uncond"]))
-            ec, eu = [v.cpu() for v in gm.forward_cfg(xs, ts, cs)]
-        else:
-            r["fwd_noise_t%d" % int(g["t"])] = C.rel_l2(gm(xg, tg, None).cpu(), g["eps"])
-            ec, eu = None, gm(xs, ts, None).cpu()
-        rows = {}
-        for i, (key, _, _, _) in enumerate(ins):
-            if ec is not None:
-                rows[key + "_c"] = C.rel_l2(ec[i], gs[key + "_c"])
-            rows[key + "_u"] = C.rel_l2(eu[i], gs[key + "_u"])
+        if g is not None:
+            xg = C.seeded_randn(100 + seed, 1, cin, S, S).to(dev)
+            tg = torch.full((1,), int(g["t"]), dtype=torch.long, device=dev)
+            if has_cls:
+                ec, eu = gm.forward_cfg(xg, tg, torch.from_numpy(g["classes"]).to(dev))
+                r["fwd_noise_t999"] = max(C.rel_l2(ec.cpu(), g["eps"]), C.rel_l2(eu.cpu(), g["eps_uncond"]))
+            else:
+                r["fwd_noise_t%d" % int(g["t"])] = C.rel_l2(gm(xg, tg, None).cpu(), g["eps"])
+        rows = C.fwd_set_deviation(gm, tag, dev)
         worst = max(rows, key=rows.get)
         r.update(fwd_set_max=rows[worst], fwd_set_argmax=worst, fwd_set_min=min(rows.values()), fwd_set_n=len(rows))
-        kw = dict(classes=ccls, strength=strength) if ccls is not None else {}
-        ch = samplers.DdimSampler(fw).sample(2, noise=x_T, steps=steps, verbose=False, **kw)
-        r["chain_samples"] = C.rel_l2(ch.samples.cpu(), gc["samples"])
-        r["chain_x0_first"] = C.rel_l2(ch.pred_x_0[0].cpu(), gc["x0_first"])
+        if fw is not None:
+            kw = dict(classes=ccls, strength=strength) if ccls is not None else {}
+            ch = samplers.DdimSampler(fw).sample(2, noise=x_T, steps=steps, verbose=False, **kw)
+            r["chain_samples"] = C.rel_l2(ch.samples.cpu(), gc["samples"])
+            r["chain_x0_first"] = C.rel_l2(ch.pred_x_0[0].cpu(), gc["x0_first"])
         if gst is not None:
             tf = {}
             for k in (1, 10, 25, 49):
@@ -141,19 +136,23 @@ def parity_checks(model_name, precisions, dev, C):
         out[prec] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in r.items()}
     del gm
     torch.cuda.empty_cache()
-    what = {"reference": "outputs of the live reference (fp32 CPU) committed under tests/golden/: %s.npz, %s.npz, %s" % (
-                gname, sname, "large128_ddim50_cfg.npz + large128_ddim50_cfg_steps.npz" if model_name == "large" else "small128_ddim10.npz"),
-            "forward_set": "x_t = q_sample(synthetic RGBD scene, t), 2 scenes x t in {0,20,250,500,750,999}%s" % (
-                " x 2 guidance branches" if has_cls else ""),
-            "chain": ("BASELINE config 2: ClassifierFreeGuidance 0.5 + DdimSampler 50 steps, eta 0, bs 2" if model_name == "large"
-                      else "BASELINE config 1 at bs 2: DdimSampler 10 steps, eta 0")}
+    what = {"reference": "outputs of the live reference (fp32 CPU) committed under tests/golden/: %s" % ", ".join(
+                n + ".npz" for n in ([gname] if gname else []) + [sname] + (["large128_ddim50_cfg", "large128_ddim50_cfg_steps"] if model_name == "large"
+                                                                        else ["small128_ddim10"] if model_name == "small" else [])),
+            "forward_set": "x_t = q_sample(synthetic RGBD scene, t), 2 scenes x %d timesteps%s%s" % (
+                len(rows) // (4 if has_cls else 2), " x 2 guidance branches" if has_cls else "",
+                {"largecond": ", conditioned through InpaintCFG.make_cond_inputs on the scene fixture's masks",
+                 "sr256": ", conditioned through SuperResCFG.make_cond_inputs on the average-pooled scene (128 x 128 centre window compared)"}.get(model_name, "")),
+            "chain": {"large": "BASELINE config 2: ClassifierFreeGuidance 0.5 + DdimSampler 50 steps, eta 0, bs 2",
+                      "small": "BASELINE config 1 at bs 2: DdimSampler 10 steps, eta 0"}.get(
+                          model_name, "none for this model here (its sampler settings have reference chains at mini size: profiles/r04_chain_parity.json)")}
     return out, what
 
 
 def within_tolerance(r):
     """The rule of the headline: every measured deviation of the mode <= PARITY_TOL."""
-    keys = [k for k in r if k.startswith("fwd_noise_")] + ["fwd_set_max", "chain_samples", "chain_x0_first"]
-    keys += ["teacher_forced_eps_max"] if "teacher_forced_eps_max" in r else []
+    keys = [k for k in r if k.startswith("fwd_noise_")] + ["fwd_set_max"]
+    keys += [k for k in ("chain_samples", "chain_x0_first", "teacher_forced_eps_max") if k in r]
     return bool(r) and all(r[k] <= PARITY_TOL for k in keys)
 
 
@@ -438,13 +437,15 @@ def main():
             # the headline mode of the c2 bench, re-verified here on the large cfg model (same rule, same in-run checks); the
             # conditional / SR models of these configs have no committed reference forwards: for them the mode is ASSUMED
             tab, what = parity_checks("large", ["fp16s"], dev, C)
-            okm = within_tolerance(tab["fp16s"])
+            tabc, whatc = parity_checks("largecond", ["fp16s"], dev, C)
+            okm = within_tolerance(tab["fp16s"]) and within_tolerance(tabc["fp16s"])
             okm = bool(int(parallel.gather_scalars(1 if okm else 0)[0]))
             a.precision = "fp16s" if okm else "bf16x3"
-            a.precision_selection = {"picked": a.precision, "verified_on": "rgbd_imagenet_adm_128_large_cfg (in this run)",
-                                     "parity": tab["fp16s"], "checks": what,
-                                     "assumed_for": "the conditional (10-channel) and super-resolution models: no reference forwards "
-                                                    "are committed for them; their 16-bit chain parity is in profiles/r04_chain_parity.json"}
+            a.precision_selection = {"picked": a.precision, "rule": "fp16s if every in-run check of BOTH 128^2 models is <= %g, else bf16x3" % PARITY_TOL,
+                                     "verified_on": {"rgbd_imagenet_adm_128_large_cfg": {"parity": tab["fp16s"], "checks": what},
+                                                     "rgbd_imagenet_adm_128_large_cond": {"parity": tabc["fp16s"], "checks": whatc}},
+                                     "sr_model": "runs in --sr-precision (bf16: what BASELINE.json names for that chain); its forward-set "
+                                                 "deviations per mode: python bench.py --model sr256"}
         return bench_c3(a, rank, world, dev, C, parallel, dist)
 
     margs = dict({"large": C.LARGE128, "small": C.SMALL128, "sr256": C.SR256}[a.model])
@@ -640,7 +641,8 @@ def main():
     if dev_tab:
         result["parity"] = dict(dev_tab[a.precision], within_tolerance=within_tolerance(dev_tab[a.precision]))
         result["forward_rel_l2_max_over_set"] = dev_tab[a.precision]["fwd_set_max"]
-        result["chain_rel_l2_vs_reference"] = dev_tab[a.precision]["chain_samples"]
+        if "chain_samples" in dev_tab[a.precision]:
+            result["chain_rel_l2_vs_reference"] = dev_tab[a.precision]["chain_samples"]
         result["parity_checks"] = parity_what
         for pp in extra:
             modes[pp]["parity"] = dict(dev_tab[pp], within_tolerance=within_tolerance(dev_tab[pp]))

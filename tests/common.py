@@ -101,3 +101,88 @@ def fwd_set_inputs(in_channels=4, S=128):
                 x[:, 4:] = x0[:, 4:]
             out.append((f"{tag}_t{t}", x.contiguous(), t, cls))
     return out
+
+
+# ---- representative forward sets of the CONDITIONAL (10-channel, InpaintCFG) and SUPER-RESOLUTION (8-channel, SuperResCFG) models ----
+FWD_SET_T_MORE = (0, 20, 500, 999)
+LARGE128_COND = dict(LARGE128, in_channels=10)       # rgbd_imagenet_adm_128_large_cond.json backbone (fp32)
+
+
+def _abar():
+    return np.cumprod(1.0 - np.linspace(1e-4, 2e-2, 1000, dtype=np.float64))
+
+
+def inpaint_cond_inputs(x, y, mask, mask_rgb, seed):
+    """InpaintCFG.make_cond_inputs (inpaint_cfg.py:24-49) with its two torch.randn_like fills drawn from torch's CPU generator
+    seeded with `seed` (rgb first, then depth): [x | mask_rgb | y_rgb masked | y_depth masked | mask]."""
+    torch.manual_seed(seed)
+    y_rgb = y[:, :3] * mask_rgb + torch.randn_like(y[:, :3]) * (1 - mask_rgb)
+    y_d = y[:, 3:] * mask + torch.randn_like(y[:, 3:]) * (1 - mask)
+    return torch.cat([x, mask_rgb, y_rgb, y_d, mask], dim=1)
+
+
+def fwd_set_inputs_cond(S=128):
+    """[(key, 10-channel model input [1,10,S,S], t, class)]: x_t = q_sample(scene, t) as in fwd_set_inputs, conditioned on the scene
+    itself seen through the visibility masks of the scene fixture (sample_all_scene_ref.npz: 88 % coverage)."""
+    import warp_common as WC
+    sc = load_golden("sample_all_scene_ref")
+    mask = torch.from_numpy(sc["cond_mask"][:1].astype(np.float32)).permute(0, 3, 1, 2)
+    mask_rgb = torch.from_numpy(sc["cond_mask_rgb"][:1].astype(np.float32)).permute(0, 3, 1, 2)
+    abar, out = _abar(), []
+    for si, (tag, kw, cls) in enumerate(FWD_SET_SCENES):
+        x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
+        for ti, t in enumerate(FWD_SET_T_MORE):
+            n = seeded_randn(7500 + 100 * si + ti, 1, 4, S, S)
+            x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
+            out.append((f"{tag}_t{t}", inpaint_cond_inputs(x, x0, mask, mask_rgb, 9000 + 10 * si + ti).contiguous(), t, cls))
+    return out
+
+
+def fwd_set_inputs_sr(S=256):
+    """[(key, 8-channel model input [1,8,S,S], t, class)]: x_t = q_sample(scene at S x S, t), conditioned on the bilinear upsample of
+    the 2x2-average-pooled scene (SuperResCFG.make_cond_inputs, sr_cfg.py:23-36)."""
+    import warp_common as WC
+    abar, out = _abar(), []
+    for si, (tag, kw, cls) in enumerate(FWD_SET_SCENES):
+        x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
+        low = torch.nn.functional.avg_pool2d(x0, 2).clamp(-1, 1)
+        up = torch.nn.functional.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False)
+        for ti, t in enumerate(FWD_SET_T_MORE):
+            n = seeded_randn(7800 + 100 * si + ti, 1, 4, S, S)
+            x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
+            out.append((f"{tag}_t{t}", torch.cat([x, up], 1).contiguous(), t, cls))
+    return out
+
+
+SR_CROP = (slice(64, 192), slice(64, 192))   # the SR fixtures store this 128 x 128 window of the 256 x 256 output
+
+
+# model tag -> (backbone args, synthetic-checkpoint seed, golden fixture, input recipe, window of the output that is stored)
+FWD_SETS = {
+    "large128": (LARGE128, 4, "large128_fwd_set", lambda: fwd_set_inputs(4, 128), None),
+    "small128": (SMALL128, 3, "small128_fwd_set", lambda: fwd_set_inputs(4, 128), None),
+    "largecond128": (LARGE128_COND, 2, "largecond128_fwd_set", fwd_set_inputs_cond, None),
+    "sr256": (SR256, 6, "sr256_fwd_set", fwd_set_inputs_sr, SR_CROP),
+}
+
+
+def fwd_set_deviation(model, tag, device="cuda"):
+    """rel-L2 of `model` (a loaded AdmUnet2d of FWD_SETS[tag]'s architecture and synthetic checkpoint, in whatever precision mode it
+    is set to) from the live reference's outputs on every row of the set -> {row: deviation}."""
+    args, _seed, gname, make, crop = FWD_SETS[tag]
+    g = load_golden(gname)
+    ins = make()
+    x = torch.cat([i[1] for i in ins]).to(device)
+    t = torch.tensor([i[2] for i in ins], device=device)
+    rows = {}
+    if args["num_classes"] is not None:
+        cls = torch.tensor([i[3] for i in ins], device=device)
+        ec, eu = [v.cpu() for v in model.forward_cfg(x, t, cls)]
+    else:
+        ec, eu = None, model(x, t, None).cpu()
+    w = (slice(None),) + crop if crop is not None else (slice(None),)
+    for i, (key, _, _, _) in enumerate(ins):
+        if ec is not None:
+            rows[key + "_c"] = rel_l2(ec[i][w], g[key + "_c"])
+        rows[key + "_u"] = rel_l2(eu[i][w], g[key + "_u"])
+    return rows

@@ -298,46 +298,35 @@ def test_config2_large128_ddim50_cfg_chain_matches_reference_golden():
     assert errs["fp16"]["samples"] < 10 * MODE_BAR["fp16"] and errs["bf16"]["samples"] < 10 * MODE_BAR["bf16"]
 
 
-def _forward_set(model_name, args, seed, gname):
-    """max / argmax over the representative forward set for every precision mode (tests/common.fwd_set_inputs)."""
+def _forward_set(tag):
+    """max / argmax over the representative forward set of model `tag` for every precision mode (tests/common.FWD_SETS)."""
+    args, seed, gname, make, _crop = C.FWD_SETS[tag]
     g = C.load_golden(gname)
-    ins = C.fwd_set_inputs(args["in_channels"], args["image_size"])
-    for key, x, _, _ in ins:   # the seeded recipe rebuilds the generator's inputs
-        assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"])))
-    x = torch.cat([i[1] for i in ins]).cuda()
-    t = torch.tensor([i[2] for i in ins]).cuda()
-    has_cls = args["num_classes"] is not None
-    cls = torch.tensor([i[3] for i in ins]).cuda() if has_cls else None
+    for key, x, _, _ in make():   # the seeded recipe rebuilds the generator's inputs
+        assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
     m, _ = build(args, seed, "fp32")
     out = {}
     for prec in ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
-        if has_cls:
-            ec, eu = [v.cpu() for v in m.forward_cfg(x, t, cls)]
-        else:
-            ec, eu = None, m(x, t, None).cpu()
-        rows = {}
-        for i, (key, _, _, _) in enumerate(ins):
-            if ec is not None:
-                rows[key + "_c"] = C.rel_l2(ec[i], g[key + "_c"])
-            rows[key + "_u"] = C.rel_l2(eu[i], g[key + "_u"])
+        rows = C.fwd_set_deviation(m, tag)
         worst = max(rows, key=rows.get)
         out[prec] = rows[worst]
-        G.report(f"fwd_set/{model_name}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), **rows)
-    print(f"forward set {model_name}: max rel-L2 vs the reference per mode:", {k: "%.3e" % v for k, v in out.items()})
+        G.report(f"fwd_set/{tag}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), **rows)
+    print(f"forward set {tag}: max rel-L2 vs the reference per mode:", {k: "%.3e" % v for k, v in out.items()})
     return out
 
 
-@pytest.mark.parametrize("model_name,args,seed,gname", [("large128", C.LARGE128, 4, "large128_fwd_set"),
-                                                        ("small128", C.SMALL128, 3, "small128_fwd_set")])
-def test_forward_set_max_deviation_per_mode(model_name, args, seed, gname):
+@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256"])
+def test_forward_set_max_deviation_per_mode(tag):
     """SURVEY.md 8(c) "full forward at t in {0, 20, 500, 999}": the inputs a sampling chain actually feeds the network --
-    x_t = the reference's q-sample of two synthetic RGBD scenes at six timesteps, both guidance branches -- against the live
-    reference's outputs (tests/golden/make_golden_fwd_set.py).  The headline claim: fp16s <= 9.5e-4 on EVERY input of the set;
-    fp16cx / fp16c / fp16 are measured (clean smooth inputs at t <= 20 put them at 1.4-2.1e-3: outside the tolerance)."""
-    e = _forward_set(model_name, args, seed, gname)
+    x_t = the reference's q-sample of two synthetic RGBD scenes at several timesteps, both guidance branches -- against the live
+    reference's outputs, for all four BASELINE backbones: large cfg and small (make_golden_fwd_set.py), the 10-channel conditional
+    model on InpaintCFG inputs and the 256^2 super-resolution model on SuperResCFG inputs (make_golden_fwd_set_more.py).  The
+    headline claim: fp16s <= 9.5e-4 on EVERY input of every set; fp16cx / fp16c / fp16 are measured (clean smooth inputs at t <= 20
+    put them at 1.4-2.1e-3: outside the tolerance)."""
+    e = _forward_set(tag)
     for prec, bar in SET_BAR.items():
-        assert e[prec] < bar, (prec, e[prec])
+        assert e[prec] < bar, (tag, prec, e[prec])
     assert e["fp16s"] < e["fp16cx"] < e["fp16c"] < e["fp16"] < 3e-3, e
     assert e["bf16"] < 3e-2
 
