@@ -319,6 +319,9 @@ def canonical_launch(name, args):
         plane = n * h * w * cout * ESZ[dt]
         extra = (plane if olo else 0) + (0 if not rlo else (plane if rm == 1 else (plane // 4 if rm == 2 else plane * 4)))
         return "ivid_conv2d", tuple(a for i, a in enumerate(args) if i not in (8, 10)), float(extra)
+    if name == "ivid_conv2d_o16":          # bf16x3 island stem that also writes the fp16 twin of its result
+        (s0, c0, s1, c1, w, b, o, _h, _l, r, rm, n, h, ww, cout, taps, tc, st) = args
+        return "ivid_conv2d", (3, s0, c0, s1, c1, w, b, o, r, rm, 0, n, h, ww, cout, taps, tc, st), float(n * h * ww * cout * 4)
     if name == "ivid_conv3x3_gn_o16":      # bf16x3 island layer that writes the fp16 twin of its result (+ fp32 when out != NULL)
         (s0, c0, s1, c1, ab, w, b, o, _h, _l, r, rm, n, h, ww, cout, st) = args
         twin = float(n * h * ww * cout * 4)

@@ -74,6 +74,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_GN_APPLY_P 22     /* ivid_gn_apply_p */
 #define IVID_OP_CONV3X3_GN_O16 23 /* ivid_conv3x3_gn_o16 */
 #define IVID_OP_GN_PARTIAL_C 24   /* ivid_gn_partial_c */
+#define IVID_OP_CONV2D_O16 25     /* ivid_conv2d_o16 */
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -195,6 +196,12 @@ int ivid_conv3x3_gn_skip_s(int dtype, const void* src0, const void* src0_lo, int
 int ivid_conv3x3_gn_o16(const void* src0, int C0, const void* src1, int C1, const float* ab, const void* weight, const float* bias,
                         void* out, void* out16_hi, void* out16_lo, const void* res, int res_mode, int N, int H, int W, int Cout,
                         float* stats, void* stream);
+
+/* ivid_conv2d for IVID_BF16X3 whose NHWC result also leaves as two fp16 planes (see ivid_conv3x3_gn_o16): the stem of the island
+ * (`input_blocks[0]`, adm.py:369) feeds the island in fp32 and the decoder's last level in the compensated 16-bit form. */
+int ivid_conv2d_o16(const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias, void* out,
+                    void* out16_hi, void* out16_lo, const void* res, int res_mode, int N, int H, int W, int Cout, int taps,
+                    int tile_cfg, float* stats, void* stream);
 
 /* The UNet's output head in one kernel (adm.py:483-487 `self.out`: GroupNorm32 -> SiLU -> zero_module(Conv2d 3x3 to
  * out_channels), adm.py:565-566): out = conv3x3(silu(src*a + b)) + bias, written as fp32 NCHW [N,Cout,H,W].

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ivid_conv3x3_gn_skip_s": (i32, [i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp,
                                      vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "ivid_f32_to_hilo": (i32, [i32, vp, vp, vp, i64, vp]),
+    "ivid_conv2d_o16": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn_o16": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv3x3_gn_out_c": (i32, [i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ivid_gn_apply_c": (i32, [i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -109,7 +110,7 @@ OP_CODES = {"ivid_conv2d": 1, "ivid_conv3x3_gn": 2, "ivid_conv3x3_gn_skip": 3, "
             "ivid_gn_finalize": 6, "ivid_gn_finalize2": 7, "ivid_gn_apply": 8, "ivid_attention": 9, "ivid_embed_inputs": 10,
             "ivid_silu_f32": 11, "ivid_stem_im2col": 12, "ivid_conv3x3_up": 13, "ivid_copy": 14, "ivid_conv2d_c": 15,
             "ivid_conv3x3_gn_skip_c": 16, "ivid_gn_apply_c": 17, "ivid_conv3x3_gn_out_c": 18, "ivid_stem_im2col_split": 19,
-            "ivid_conv3x3_gn_skip_s": 20, "ivid_f32_to_hilo": 21, "ivid_gn_apply_p": 22, "ivid_conv3x3_gn_o16": 23, "ivid_gn_partial_c": 24}
+            "ivid_conv3x3_gn_skip_s": 20, "ivid_f32_to_hilo": 21, "ivid_gn_apply_p": 22, "ivid_conv3x3_gn_o16": 23, "ivid_gn_partial_c": 24, "ivid_conv2d_o16": 25}
 
 
 class Slot(C.Union):

@@ -52,6 +52,10 @@ struct ConvArgs {
   // read the hi plane alone (it IS the rounded operand); residual adds and GroupNorm kernels read hi + lo.
   char* out_lo;         // optional lo plane of the NHWC output
   const char* res_lo;   // optional lo plane of the residual source
+  // IVID_BF16X3 only (fp32 storage): optional fp16 twin of the NHWC output, hi = fp16(v), lo = fp16(v - hi) -- the form the
+  // 16-bit part of the network reads (the stem of the fp16s mode's split-precision island, ivid_conv2d_o16)
+  char* out16_hi;
+  char* out16_lo;
 };
 
 // UP4: the phase-decomposed "nearest x2 upsample + conv 3x3" form (taps == 4, ivid_conv3x3_up) -- a separate
@@ -412,6 +416,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
             mo = ((size_t)img * (2 * p.H) + 2 * y + py) * (2 * p.W) + 2 * x + px;
           }
           *(vec_t*)(p.out + (mo * Cout + n) * sizeof(T)) = ov;
+          if constexpr (IsSplit<T>::value) {
+            if (p.out16_hi) {   // fp32 storage (VE = 4): 8-byte stores of the fp16 twin
+              f16x4 th, tl;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                th[e] = (_Float16)v[e];
+                tl[e] = (_Float16)(v[e] - (float)th[e]);
+              }
+              *(f16x4*)(p.out16_hi + (mo * Cout + n) * 2) = th;
+              *(f16x4*)(p.out16_lo + (mo * Cout + n) * 2) = tl;
+            }
+          }
           float sv[VE];
           vec_to_f32<T>(ov, sv);  // statistics of the values the consumer will actually read
           if constexpr (LO) {
@@ -538,7 +554,7 @@ static int ivid_conv_pick_tile(long long M, int Cout, int tile_cfg, int nmult = 
 static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int C1, const void* weight,
                       const float* bias, void* out, const void* res, int res_mode, int out_mode, int N, int H,
                       int W, int Cout, int taps, int tile_cfg, float* stats, void* stream, void* out_lo = nullptr,
-                      const void* res_lo = nullptr) {
+                      const void* res_lo = nullptr, void* out16_hi = nullptr, void* out16_lo = nullptr) {
   const int esz = ivid_esz(dtype);
   if (!esz) return ivid_set_error("conv: bad dtype", hipSuccess);
   const int bke = 128 / esz, ve = 16 / esz;
@@ -558,6 +574,9 @@ static int conv2d_any(int dtype, const void* src0, int C0, const void* src1, int
   a.src0 = (const char*)src0; a.src1 = (const char*)src1; a.w = (const char*)weight; a.bias = bias;
   a.out = (char*)out; a.res = (const char*)res; a.zero = (const char*)ivid_zero_page();
   a.out_lo = (char*)out_lo; a.res_lo = (const char*)res_lo;
+  a.out16_hi = (char*)out16_hi; a.out16_lo = (char*)out16_lo;
+  if (out16_hi && (dtype != IVID_BF16X3 || !out16_lo || out_mode != 0 || taps == 4))
+    return ivid_set_error("conv2d_o16: IVID_BF16X3, NHWC output, both fp16 planes", hipSuccess);
   if (!a.zero) return -1;
   a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.taps = taps;
   a.res_mode = res_mode; a.out_mode = out_mode; a.M = N * H * W; a.ntiles_n = 0; a.ntiles_total = 0; a.nt_phase = 0;
@@ -609,6 +628,18 @@ extern "C" int ivid_conv2d_c(int dtype, const void* src0, int C0, const void* sr
   if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
   return conv2d_any(dtype, src0, C0, src1, C1, weight, bias, out, res, res_mode, out_mode, N, H, W, Cout, taps, tile_cfg, stats,
                     stream, out_lo, res_lo);
+}
+
+// ivid_conv2d for IVID_BF16X3 (fp32 storage, split-bf16 MFMA) whose NHWC result ALSO leaves as two fp16 planes hi + lo: the stem
+// of the fp16s mode's split-precision island (adm.py:369) feeds the island in fp32 and the decoder's last level, through the
+// skip stash, in the compensated 16-bit form -- without a conversion pass.
+extern "C" int ivid_conv2d_o16(const void* src0, int C0, const void* src1, int C1, const void* weight, const float* bias, void* out,
+                               void* out16_hi, void* out16_lo, const void* res, int res_mode, int N, int H, int W, int Cout, int taps,
+                               int tile_cfg, float* stats, void* stream) {
+  if (taps != 1 && taps != 9) return ivid_set_error("conv: taps must be 1 or 9", hipSuccess);
+  if (!out || !out16_hi || !out16_lo) return ivid_set_error("conv2d_o16: the fp32 output and both fp16 planes are required", hipSuccess);
+  return conv2d_any(IVID_BF16X3, src0, C0, src1, C1, weight, bias, out, res, res_mode, 0, N, H, W, Cout, taps, tile_cfg, stats, stream,
+                    nullptr, nullptr, out16_hi, out16_lo);
 }
 
 // Upsample2d (nearest x2, adm.py:70-83 inside an `up` ResBlock's h_upd, adm.py:203-206) followed by the block's Conv2d 3x3,

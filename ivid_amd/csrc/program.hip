@@ -81,6 +81,9 @@ int run_op(const Op& o, void* s) {
                                     CP(27), CP(28), s);
     case IVID_OP_F32_TO_HILO:
       return ivid_f32_to_hilo(I(0), CFP(1), P(2), P(3), o.a[4].i, s);
+    case IVID_OP_CONV2D_O16:
+      return ivid_conv2d_o16(CP(0), I(1), CP(2), I(3), CP(4), CFP(5), P(6), P(7), P(8), CP(9), I(10), I(11), I(12), I(13), I(14), I(15),
+                             I(16), FP(17), s);
     case IVID_OP_CONV3X3_GN_O16:
       return ivid_conv3x3_gn_o16(CP(0), I(1), CP(2), I(3), CFP(4), CP(5), CFP(6), P(7), P(8), P(9), CP(10), I(11), I(12), I(13), I(14),
                                  I(15), FP(16), s);

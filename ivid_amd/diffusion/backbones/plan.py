@@ -628,8 +628,17 @@ class UNetPlan:
         self._rec("ivid_stem_im2col_split" if self.comp else "ivid_stem_im2col", self.dtype, self.x_in.data_ptr(), self.bsrc, n,
                   sp.in_channels, S, S, w.stem_k, xin.ptr)
         h = self._new(n, S, sp.stem_out, stats=True, trunk=True)
-        self._conv(self.dtype, xin.ptr, w.stem_k, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 1,
-                   out_act=h, out_lo=h.lo_ptr)
+        if island and self.island_o16:
+            # the island's stem: fp32 for the island + its fp16 twin for the decoder's last level (through the skip stash)
+            h.twin = self._new16(n, S, sp.stem_out)
+            if h.stats is not None:
+                h.stats_blk = self.lib.ivid_conv2d_stats_block(n, S, S, sp.stem_out, self.tile_cfg)
+            self._rec("ivid_conv2d_o16", xin.ptr, w.stem_k, None, 0, self.w["input_blocks.0.0.weight"].data_ptr(),
+                      self.w["input_blocks.0.0.bias"].data_ptr(), h.ptr, h.twin.ptr, h.twin.lo_ptr, None, 0, n, S, S, sp.stem_out, 1,
+                      self.tile_cfg, h.stats.data_ptr() if h.stats is not None else None)
+        else:
+            self._conv(self.dtype, xin.ptr, w.stem_k, None, 0, "input_blocks.0.0", h.ptr, None, 0, 0, n, S, S, sp.stem_out, 1,
+                       out_act=h, out_lo=h.lo_ptr)
         self._free(xin)
         self._tap("stem", h)
         stash = [h]

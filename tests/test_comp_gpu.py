@@ -480,3 +480,32 @@ def test_gn_partial_c_sums_hi_plus_lo(dtype):
     assert float((got_s - v.sum((2, 3))).abs().max()) < 2e-3 and float((got_q / (v * v).sum((2, 3)) - 1).abs().max()) < 1e-5
     hi_only = torch.cat([G.rounded(x0, dtype), G.rounded(x1, dtype)], 1).double()
     assert float(((hi_only * hi_only).sum((2, 3))[:, :C0] / got_q[:, :C0] - 1).abs().max()) > 1e-5     # the lo plane is in the sums
+
+
+@pytest.mark.parametrize("taps,tile", [(1, 0), (9, 1), (1, 4)])
+def test_conv2d_o16_writes_the_fp16_twin_of_the_bf16x3_result(taps, tile):
+    """ivid_conv2d_o16: the IVID_BF16X3 implicit GEMM whose NHWC result also leaves as fp16 hi + lo planes: the fp32 output and the
+    GroupNorm partials are bit-identical to ivid_conv2d's, the planes are exactly fp16(v) and fp16(v - hi)."""
+    L = G.lib()
+    N, H, W, C0, Cout = 2, 16, 16, 64, 128
+    k = 3 if taps == 9 else 1
+    x = common.seeded_randn(61, N, C0, H, W)
+    w = common.seeded_randn(62, Cout, C0, k, k) / np.sqrt(C0 * taps)
+    bias = common.seeded_randn(63, Cout) * 0.1
+    xd, bd = G.to_nhwc(x, 3), bias.cuda()
+    wp = G.pack_w(w.permute(0, 2, 3, 1).reshape(Cout, -1), 3)
+    blk = L.load().ivid_conv2d_stats_block(N, H, W, Cout, tile)
+    ref, st0 = torch.full((N, H, W, Cout), float("nan"), device="cuda"), torch.full((N * H * W // blk, Cout, 2), float("nan"), device="cuda")
+    L.call("ivid_conv2d", 3, L.ptr(xd), C0, None, 0, L.ptr(wp), L.ptr(bd), L.ptr(ref), None, 0, 0, N, H, W, Cout, taps, tile, L.ptr(st0), G.stream())
+    out, st = torch.full_like(ref, float("nan")), torch.full_like(st0, float("nan"))
+    hi = torch.full((N, H, W, Cout), float("nan"), device="cuda", dtype=torch.float16)
+    lo = torch.full_like(hi, float("nan"))
+    L.call("ivid_conv2d_o16", L.ptr(xd), C0, None, 0, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(hi), L.ptr(lo), None, 0, N, H, W, Cout, taps, tile,
+           L.ptr(st), G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(st, st0)
+    assert torch.equal(hi, ref.half()) and torch.equal(lo, (ref - ref.half().float()).half())
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=k // 2).float()
+    assert common.rel_l2(joined(hi, lo), want) < 4e-5
+    assert L.load().ivid_conv2d_o16(L.ptr(xd), C0, None, 0, L.ptr(wp), L.ptr(bd), L.ptr(out), L.ptr(hi), None, None, 0, N, H, W, Cout, taps, tile,
+                                    None, G.stream()) != 0

@@ -329,11 +329,12 @@ def test_bench_flop_accounting_adds_up_to_the_reference_count(monkeypatch):
     pl = P.UNetPlan(spec, P.PackedWeights(spec, sd, "meta", _lib.F16, comp=3), "meta", bsrc, True)
     prof = [(name, a, 1.0) for _fn, name, a in pl.launches]
     names = [n for n, _, _ in prof]
-    # island hand-over: the stem output through ivid_f32_to_hilo, the two ResBlock outputs written as fp16 twins by their producers
-    assert names.count("ivid_f32_to_hilo") == 1 and names.count("ivid_conv3x3_gn_o16") == 2 and names.count("ivid_conv3x3_gn_skip_s") >= 9
+    # island hand-over: all three tensors leave as fp16 twins written by their own producers (no conversion pass)
+    assert names.count("ivid_f32_to_hilo") == 0 and names.count("ivid_conv2d_o16") == 1     # the stem writes its own twin too
+    assert names.count("ivid_conv3x3_gn_o16") == 2 and names.count("ivid_conv3x3_gn_skip_s") >= 9
     o16 = [a for n, a, _ in prof if n == "ivid_conv3x3_gn_o16"]
     assert o16[0][7] is not None and o16[1][7] is None       # only the first block's fp32 form has a reader (the second block)
     fam, other = bench.kernel_table(prof, "fp16s")
     launched = sum(f["flop"] for f in fam.values())
     assert abs((launched + shared) / ref - 1.0) < 5e-3, (launched + shared) / ref
-    assert "ivid_f32_to_hilo" in other
+    assert "ivid_f32_to_hilo" not in other

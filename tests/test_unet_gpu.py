@@ -356,15 +356,15 @@ def test_config2_teacher_forced_eps_on_the_chains_own_inputs():
 
 def test_fp16s_plan_runs_the_first_level_as_a_split_island_and_every_skip_conv_in_split_precision():
     """Structure of the fp16s launch plan: stem + first encoder level with fp32 storage (IVID_BF16X3 launches), handed over to the
-    16-bit part as fp16 hi + lo planes (the stem output through ivid_f32_to_hilo, the two ResBlock outputs written by their own
-    producers, ivid_conv3x3_gn_o16), every 1x1 skip_connection either inside ivid_conv3x3_gn_skip_s or as three chained
+    16-bit part as fp16 hi + lo planes written by their own producers (ivid_conv2d_o16 for the stem, ivid_conv3x3_gn_o16 for the two
+    ResBlock outputs; IVID_NO_ISLAND_O16=1 converts them with ivid_f32_to_hilo instead), every 1x1 skip_connection either inside ivid_conv3x3_gn_skip_s or as three chained
     ivid_conv2d_c launches (x_hi.w_hi, + x_lo.w_hi, + x_hi.w_lo)."""
     from ivid_amd import _lib
     m, _ = build(C.LARGE128, 4, "fp16s")
     plan = m.plan(1, False)
     names = [name for _, name, _ in plan.launches]
-    assert names.count("ivid_f32_to_hilo") == 1 and names.count("ivid_conv3x3_gn_o16") == 2
-    first = names.index("ivid_f32_to_hilo")
+    assert names.count("ivid_f32_to_hilo") == 0 and names.count("ivid_conv2d_o16") == 1 and names.count("ivid_conv3x3_gn_o16") == 2
+    first = len(names) - 1 - names[::-1].index("ivid_conv3x3_gn_o16") + 1          # first launch behind the island
     island = [(n, a) for _, n, a in plan.launches[:first] if n in ("ivid_conv3x3_gn", "ivid_conv3x3_gn_skip", "ivid_conv2d", "ivid_gn_apply")]
     assert sum(1 for n, a in island if n == "ivid_conv3x3_gn" and a[0] == _lib.BF16X3) == 2        # the in_layers convs of the two ResBlocks
     assert not any(a[0] == _lib.BF16X3 for _, n, a in plan.launches[first:] if n.startswith("ivid_conv"))
