@@ -24,7 +24,7 @@ HIP launch plan (plan.py) on weights repacked once per precision:
                         trunk itself is that convolution's operand) + the stem and the first encoder level as a split-precision
                         island (fp32 storage, bf16 hi + lo operands, 3 MFMAs per product).  Measured on the representative
                         forward set (q-sampled scenes, t in {0..999}): max 8.8e-4 (large) / 8.3e-4 (small), where fp16cx is
-                        1.45e-3 and fp16c 1.66e-3 -- the fastest mode INSIDE the 1e-3 tolerance per forward (18 % slower than fp16cx)
+                        1.45e-3 and fp16c 1.66e-3 -- the fastest mode INSIDE the 1e-3 tolerance per forward (15 % slower than fp16cx)
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
 `use_fp16=True` configs select "fp16s" (the reference's fp16 torso, made to meet the fp32 tolerance on every input); override with the
 extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
