@@ -25,10 +25,12 @@ faster but outside the tolerance are timed beside it in `other_modes` with their
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline          the dominant kernel (conv3x3_fused_kernel): algorithmic FLOPs of its launches in one forward /
                     HIP-event time of those launches (events on the plan's stream), against the dense bf16 MFMA peak
+                    + `traffic` (HBM bytes per launch) and `mfma_util` (MFMA-busy share, effective clock) from the committed
+                    PMC passes of this command (profiles/r04_pmc_*_<mode>.json, tied to the kernel-source hash)
   roofline_kernels  the same for every kernel family of the forward (weakest visible in the line itself)
-  parity_mode       the same step timed in the precision mode whose measured deviation from the reference is <= 1e-3
-                    (bf16x3: split-bf16 operands, 3 MFMAs per product), with `rel_l2_vs_reference` measured in THIS run
-                    against the committed reference output tests/golden/large128_fwd.npz
+  parity            every deviation of the headline mode from the live reference's outputs, measured in THIS run
+  other_modes       the other modes timed on the same workload, each with its own `parity` record and `within_tolerance`
+  parity_mode       the same for bf16x3 (split-bf16 operands, 3 MFMAs per product: 2e-5 everywhere)
   cpu_baseline      the reference (if /root/reference is importable: kind "reference") or the fp32 CPU oracle
                     (kind "port") timed on the host cores of rank 0 on a bounded sample
 """
