@@ -75,6 +75,7 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_CONV3X3_GN_O16 23 /* ivid_conv3x3_gn_o16 */
 #define IVID_OP_GN_PARTIAL_C 24   /* ivid_gn_partial_c */
 #define IVID_OP_CONV2D_O16 25     /* ivid_conv2d_o16 */
+#define IVID_OP_LAST 25
 int ivid_program_create(void** handle_out);
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
 int ivid_program_num_ops(void* handle);
@@ -91,6 +92,17 @@ int ivid_unet_bind(void* handle, void* x_in, long long x_bytes, void* t_in, void
  * row; out NULL = leave the result in the program's own output buffer.  Everything is enqueued on `stream`. */
 int ivid_unet_forward(void* handle, const void* x, const void* times, const void* classes, void* out, int use_graph,
                       void* stream);
+/* A planned forward as a FILE: `AdmUnet2d.plan(...).export_engine()` (ivid_amd/diffusion/backbones/engine.py, layout documented
+ * there) freezes one plan -- model weights repacked for one precision mode, one (batch, stacked-CFG) shape, the launch list with
+ * relocatable pointer arguments.  ivid_unet_load builds the program from that file held in HOST memory: one device allocation for
+ * every buffer, constants uploaded, pointers relocated, boundary bound.  What a serving host without Python does in place of the
+ * reference's `AdmUnet2d(**args)` + `load_state_dict` (adm.py:385-524, inference/sample.py:35-56): load, then ivid_unet_forward
+ * per call, ivid_program_destroy at the end (frees the allocation).  Malformed files are rejected with an error, never trusted. */
+int ivid_unet_load(const void* blob, long long nbytes, void** handle_out);
+/* Boundary of a bound / loaded program: rows of x, whether `classes` is read, bytes of x and of the output, dims[4] = output rows
+ * (batch, or 2 x batch for a stacked classifier-free-guidance plan: conditional rows first), in channels, out channels, image size
+ * (zeros for a program bound by hand).  Any pointer may be NULL. */
+int ivid_unet_info(void* handle, int* batch, int* has_classes, long long* x_bytes, long long* out_bytes, int* dims);
 
 /* ---- convolution / linear: nn.Conv2d 3x3 pad1 (adm.py:160,182,369,486), nn.Conv2d 1x1 skip (adm.py:190),
  *      nn.Conv1d k=1 qkv/proj_out (adm.py:275,278), nn.Linear (adm.py:176,359,361) ----

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ivid_program_destroy": (i32, [vp]),
     "ivid_unet_bind": (i32, [vp, vp, i64, vp, vp, i32, vp, i64]),
     "ivid_unet_forward": (i32, [vp, vp, vp, vp, vp, i32, vp]),
+    "ivid_unet_load": (i32, [vp, i64, vp]),
+    "ivid_unet_info": (i32, [vp, vp, vp, vp, vp, vp]),
     "ivid_conv2d": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_conv2d_stats_block": (i32, [i32, i32, i32, i32, i32]),
     "ivid_conv2d_c": (i32, [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

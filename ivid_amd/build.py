@@ -58,7 +58,29 @@ def build_all(verbose=True, force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    _build_host_example(verbose)
     return LIB
+
+
+HOST_SRC = os.path.join(os.path.dirname(HERE), "examples", "unet_engine_host.c")
+HOST_BIN = os.path.join(LIBDIR, "unet_engine_host")
+
+
+def _build_host_example(verbose):
+    """examples/unet_engine_host.c: a C host that runs a planned forward from an engine file through the C ABI alone (plain C
+    compiler, linked against libivid_hip.so and the HIP runtime)."""
+    if not os.path.exists(HOST_SRC):
+        return
+    if os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) > max(os.path.getmtime(HOST_SRC), os.path.getmtime(LIB)):
+        return
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O2", "-std=c11", "-I" + os.path.join(rocm, "include"), HOST_SRC, "-o", HOST_BIN, "-L" + LIBDIR, "-livid_hip",
+           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host example failed to build:\n{r.stdout}\n{r.stderr}")
 
 
 if __name__ == "__main__":

@@ -23,6 +23,8 @@ struct Program {
   float* x_in = nullptr; long long x_bytes = 0;
   long long* t_in = nullptr; long long* c_in = nullptr; int batch = 0;
   float* out = nullptr; long long out_bytes = 0;
+  void* slab = nullptr; long long slab_bytes = 0;   // ivid_unet_load: the program owns every buffer its launches touch
+  int dims[4] = {0, 0, 0, 0};                        // engine files: output rows, in / out channels, image size
 };
 
 #define P(k) ((void*)(intptr_t)o.a[k].i)
@@ -195,10 +197,114 @@ extern "C" int ivid_unet_forward(void* handle, const void* x, const void* times,
   return 0;
 }
 
+// ---- engine files: a planned forward frozen by ivid_amd/diffusion/backbones/engine.py (layout documented there) ----
+namespace {
+struct Reader {
+  const unsigned char* b; size_t n; size_t p = 0; bool ok = true;
+  template <class T> T get() {
+    T v{};
+    if (!ok || n - p < sizeof(T) || p > n) { ok = false; return v; }
+    memcpy(&v, b + p, sizeof(T)); p += sizeof(T);
+    return v;
+  }
+};
+struct EngBuf { int kind; unsigned long long nbytes, src, dev; };
+}  // namespace
+
+// Build a UNet program from an engine file held in HOST memory: one device allocation holds every buffer (arena scratch,
+// repacked weights, the static inputs and the output), constants are uploaded, pointer arguments are relocated, the model
+// boundary is bound.  The handle is what ivid_unet_forward / ivid_program_destroy take; destroy frees the allocation.
+extern "C" int ivid_unet_load(const void* blob, long long nbytes, void** handle_out) {
+  if (!blob || nbytes < 64 || !handle_out) return ivid_set_error("unet_load: bad arguments", hipSuccess);
+  Reader r{(const unsigned char*)blob, (size_t)nbytes};
+  if (memcmp(r.b, "IVIDENG1", 8) != 0) return ivid_set_error("unet_load: not an ivid engine file (magic)", hipSuccess);
+  r.p = 8;
+  const unsigned batch = r.get<unsigned>(), has_cls = r.get<unsigned>();
+  const unsigned rows = r.get<unsigned>(), cin = r.get<unsigned>(), cout = r.get<unsigned>(), size = r.get<unsigned>();
+  const unsigned long long x_bytes = r.get<unsigned long long>(), out_bytes = r.get<unsigned long long>();
+  const unsigned ix = r.get<unsigned>(), it = r.get<unsigned>(), ic = r.get<unsigned>(), io = r.get<unsigned>();
+  const unsigned nb = r.get<unsigned>();
+  if (!r.ok || nb == 0 || nb > (1u << 20) || batch == 0) return ivid_set_error("unet_load: truncated or malformed header", hipSuccess);
+  std::vector<EngBuf> bufs(nb);
+  unsigned long long total = 0;
+  for (unsigned k = 0; k < nb; ++k) {
+    EngBuf& e = bufs[k];
+    e.kind = r.get<unsigned char>(); e.nbytes = r.get<unsigned long long>(); e.src = r.get<unsigned long long>();
+    if (!r.ok || e.kind > 1 || e.nbytes > (1ull << 40)) return ivid_set_error("unet_load: malformed buffer table", hipSuccess);
+    if (e.kind == 1 && (e.src > (unsigned long long)nbytes || e.nbytes > (unsigned long long)nbytes - e.src))
+      return ivid_set_error("unet_load: constant data outside the file", hipSuccess);
+    e.dev = total;
+    total += (e.nbytes + 255) / 256 * 256 + 256;   // every buffer starts on a 256-byte boundary, as the arena's do
+  }
+  if (ix >= nb || it >= nb || io >= nb || (has_cls && ic >= nb)) return ivid_set_error("unet_load: boundary buffer index out of range", hipSuccess);
+  if (x_bytes != 4ull * batch * cin * size * size || out_bytes != 4ull * rows * cout * size * size || (rows != batch && rows != 2 * batch))
+    return ivid_set_error("unet_load: boundary sizes disagree with the stated shape", hipSuccess);
+  if (bufs[ix].nbytes < x_bytes || bufs[io].nbytes < out_bytes || bufs[it].nbytes < 8ull * batch || (has_cls && bufs[ic].nbytes < 8ull * batch))
+    return ivid_set_error("unet_load: boundary buffer smaller than the boundary", hipSuccess);
+  const unsigned nops = r.get<unsigned>();
+  if (!r.ok || nops > (1u << 20)) return ivid_set_error("unet_load: malformed op count", hipSuccess);
+  Program* p = new Program();
+  p->ops.reserve(nops);
+  const char* bad = nullptr;
+  // pass 1: decode with pointer slots holding (buffer, offset) -> relocate after the allocation
+  std::vector<std::pair<size_t, int>> relocs;   // (op, arg)
+  for (unsigned k = 0; k < nops && !bad; ++k) {
+    Op o;
+    o.code = (int)r.get<unsigned>(); o.nargs = (int)r.get<unsigned>();
+    if (!r.ok || o.nargs < 0 || o.nargs > 32 || o.code < 1 || o.code > IVID_OP_LAST) { bad = "unet_load: malformed op"; break; }
+    for (int a = 0; a < o.nargs; ++a) {
+      const unsigned char tag = r.get<unsigned char>();
+      if (tag == 0) o.a[a].i = r.get<long long>();
+      else if (tag == 1) o.a[a].f = r.get<double>();
+      else if (tag == 3) { r.get<long long>(); o.a[a].i = 0; }
+      else if (tag == 2) {
+        const unsigned bi = r.get<unsigned>(); r.get<unsigned>();
+        const unsigned long long off = r.get<unsigned long long>();
+        if (!r.ok || bi >= nb || off > bufs[bi].nbytes) { bad = "unet_load: pointer argument outside its buffer"; break; }
+        o.a[a].i = (long long)(bufs[bi].dev + off);
+        relocs.push_back({p->ops.size(), a});
+      } else { bad = "unet_load: unknown argument tag"; break; }
+      if (!r.ok) { bad = "unet_load: truncated op list"; break; }
+    }
+    if (!bad) p->ops.push_back(o);
+  }
+  if (bad) { delete p; return ivid_set_error(bad, hipSuccess); }
+  hipError_t e = hipMalloc(&p->slab, (size_t)total);
+  if (e != hipSuccess) { p->slab = nullptr; ivid_program_destroy(p); return ivid_set_error("unet_load: hipMalloc of the engine's buffers", e); }
+  p->slab_bytes = (long long)total;
+  char* base = (char*)p->slab;
+  for (unsigned k = 0; k < nb && e == hipSuccess; ++k)
+    if (bufs[k].kind == 1 && bufs[k].nbytes) e = hipMemcpy(base + bufs[k].dev, r.b + bufs[k].src, (size_t)bufs[k].nbytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { ivid_program_destroy(p); return ivid_set_error("unet_load: constant upload", e); }
+  for (auto& rc : relocs) p->ops[rc.first].a[rc.second].i += (long long)(intptr_t)base;
+  p->x_in = (float*)(base + bufs[ix].dev); p->x_bytes = (long long)x_bytes;
+  p->t_in = (long long*)(base + bufs[it].dev);
+  p->c_in = has_cls ? (long long*)(base + bufs[ic].dev) : nullptr;
+  p->batch = (int)batch;
+  p->out = (float*)(base + bufs[io].dev); p->out_bytes = (long long)out_bytes;
+  p->dims[0] = (int)rows; p->dims[1] = (int)cin; p->dims[2] = (int)cout; p->dims[3] = (int)size;
+  *handle_out = p;
+  return 0;
+}
+
+// The boundary of a bound / loaded UNet program: rows of x, whether it takes classes, bytes of x and of the output;
+// dims[4] = output rows, in channels, out channels, image size (zeros for a program bound by hand).
+extern "C" int ivid_unet_info(void* handle, int* batch, int* has_classes, long long* x_bytes, long long* out_bytes, int* dims) {
+  Program* p = (Program*)handle;
+  if (!p || !p->x_in) return ivid_set_error("unet_info: program has no bound boundary", hipSuccess);
+  if (batch) *batch = p->batch;
+  if (has_classes) *has_classes = p->c_in ? 1 : 0;
+  if (x_bytes) *x_bytes = p->x_bytes;
+  if (out_bytes) *out_bytes = p->out_bytes;
+  if (dims) memcpy(dims, p->dims, sizeof(p->dims));
+  return 0;
+}
+
 extern "C" int ivid_program_destroy(void* handle) {
   Program* p = (Program*)handle;
   if (!p) return 0;
   if (p->graph) hipGraphExecDestroy(p->graph);
+  if (p->slab) hipFree(p->slab);
   delete p;
   return 0;
 }

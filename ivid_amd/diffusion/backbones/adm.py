@@ -209,6 +209,16 @@ class AdmUnet2d(nn.Module):
         self._plans[key] = p
         return p
 
+    def export_engine(self, batch, stacked=False, path=None):
+        """Freeze the launch plan of one (batch, stacked-CFG) shape -- in the model's current precision mode, with its repacked
+        weights -- into an engine file (bytes; written to `path` if given) that `ivid_unet_load` runs WITHOUT Python
+        (include/ivid_hip.h; examples/unet_engine_host.c; diffusion/backbones/engine.py for the layout)."""
+        blob = self.plan(batch, stacked).export_engine()
+        if path is not None:
+            with open(path, "wb") as f:
+                f.write(blob)
+        return blob
+
     # ---- reference-compatible forward ----
     @torch.no_grad()
     def forward(self, x, times, classes=None):

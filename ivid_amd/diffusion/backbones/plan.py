@@ -763,6 +763,12 @@ class UNetPlan:
             self.graph = gh
         _lib.call("ivid_graph_launch", self.graph, C.c_void_p(stream))
 
+    def export_engine(self):
+        """This plan as an engine file (bytes) for `ivid_unet_load`: a non-Python host runs the forward through the C ABI alone
+        (diffusion/backbones/engine.py)."""
+        from .engine import export_engine
+        return export_engine(self)
+
     def profile_eager(self):
         """One eager forward with a HIP-event pair around EVERY launch (on the plan's stream, where the
         kernels run).  Returns [(c_abi_name, args, milliseconds)] — bench.py derives the per-kernel-family
