@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--out", default="gpurun_out/error_layers.json")
     ap.add_argument("--rows", default="", help="comma list of row indices to keep (default all)")
     ap.add_argument("--combos-only", action="store_true", help="skip the per-site sweep")
+    ap.add_argument("--extra", default="", help="extra combos on top of cx+skip: 'name=K@prefix,K@prefix;name=...' -- kind K (W / A) is kept "
+                    "EXACT at every site whose name starts with prefix (e.g. W@input_blocks.2.0.,A@input_blocks.1.0.in_layers)")
+    ap.add_argument("--only-extra", action="store_true", help="run the --extra combos only")
     a = ap.parse_args()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     torch.backends.cudnn.allow_tf32 = False
@@ -169,6 +172,12 @@ def main():
               "c+skip+X(ib1,2,3)": selx(ib(1, 2, 3), "WAHQF"),
               "cx+X(ib1,2,3)": lambda k, s: k in "WAQ" and not any(s.startswith(p) for p in ib(1, 2, 3)),
               "cx+skip+X(ib1,2,3)+W(ob12,13,14)": (lambda k, s: selx(ib(1, 2, 3))(k, s) and not (k == "W" and any(s.startswith(p) for p in ob(12, 13, 14))))}
+    if a.only_extra:
+        combos = {}
+    for spec in filter(None, a.extra.split(";")):
+        name, items = spec.split("=", 1)
+        fixes = [tuple(it.split("@", 1)) for it in items.split(",")]
+        combos[name] = (lambda fx: lambda k, s: k in "WAQ" and not skip(s) and not any(k == kk and s.startswith(pp) for kk, pp in fx))(fixes)
     for name, pred in combos.items():
         res["combos"][name] = rows_rel(forward(sd, args, x, t, cl, Sites(pred)), ref)
         print(name, f"max {max(res['combos'][name]):.3e}", flush=True)
