@@ -48,15 +48,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
 # flops (its 3 MFMAs per product are overhead, not work)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "fp16s": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "fp16s": 2500.0, "fp16cs": 2500.0, "fp16sa": 2500.0,
+               "bf16x3": 2500.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
-DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2}
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2}
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
 # `dtype` of the bench line = the arithmetic type of the MFMA operands; `precision_mode` = the mode of this package
-ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "fp16s": "fp16", "bf16x3": "bf16"}
+ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "fp16s": "fp16", "fp16cs": "fp16",
+         "fp16sa": "fp16", "bf16x3": "bf16"}
 MODE_NOTE = {
     "fp32": "fp32 storage, exact fp32 MFMA",
     "bf16": "bf16 storage and MFMA operands, fp32 accumulate",
@@ -65,6 +67,10 @@ MODE_NOTE = {
     "fp16cx": "fp16c + lo planes also feed the fused kernels' GroupNorm, h1 compensated too",
     "fp16s": "fp16cx + every 1x1 skip_connection in split precision (3 MFMA passes) + stem and first encoder level as a "
              "split-precision island (fp32 storage, bf16 hi + lo operands, 3 MFMA passes)",
+    "fp16cs": "fp16s without its split-precision island (stem and first encoder level in plain fp16cx form): inside the tolerance "
+              "only on inputs that carry diffusion noise (t >= 250 on the representative forward set)",
+    "fp16sa": "adaptive (opt-in): fp16s for forwards at t < 250 (IVID_ADAPTIVE_T), fp16cs (no island) for forwards the sampler "
+              "announces with t >= 250 -- every row of the forward set is checked in the mode its timestep selects",
     "bf16x3": "fp32 storage; operands split into bf16 hi + lo, 3 bf16 MFMAs per product",
 }
 PARITY_TOL = 1e-3                                           # BASELINE.json north_star: outputs within 1e-3 of the reference
@@ -113,6 +119,7 @@ def parity_checks(model_name, precisions, dev, C):
         if g is not None:
             xg = C.seeded_randn(100 + seed, 1, cin, S, S).to(dev)
             tg = torch.full((1,), int(g["t"]), dtype=torch.long, device=dev)
+            gm.note_timestep(int(g["t"]))     # what a sampler does before its model call (only the adaptive mode looks at it)
             if has_cls:
                 ec, eu = gm.forward_cfg(xg, tg, torch.from_numpy(g["classes"]).to(dev))
                 r["fwd_noise_t999"] = max(C.rel_l2(ec.cpu(), g["eps"]), C.rel_l2(eu.cpu(), g["eps_uncond"]))
@@ -131,6 +138,7 @@ def parity_checks(model_name, precisions, dev, C):
             for k in (1, 10, 25, 49):
                 xk = torch.from_numpy(gst[f"x_step{k}"]).to(dev)
                 tk = torch.full((xk.shape[0],), int(gst[f"t_step{k}"]), dtype=torch.long, device=dev)
+                gm.note_timestep(int(gst[f"t_step{k}"]))
                 ec2, eu2 = gm.forward_cfg(xk, tk, ccls)
                 tf[k] = C.rel_l2(((1 + strength) * ec2 - strength * eu2).cpu(), gst[f"eps_step{k}"])
             r["teacher_forced_eps_max"] = max(tf.values())
@@ -169,7 +177,7 @@ def parse_args(argv=None):
                     help="auto: the fastest mode within 1e-3 of the reference on every in-run check (forward set, chain, teacher-forced eps)")
     ap.add_argument("--parity-precision", default="bf16x3", choices=sorted(DTYPE_CODE),
                     help="second, parity-grade mode timed beside the headline ('none' via --no-parity-mode)")
-    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c,fp16cx,fp16s",
+    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c,fp16cx,fp16s,fp16sa",
                     help="comma list of further modes timed briefly beside the headline (fp16 = the reference's use_fp16 torso)")
     ap.add_argument("--guidance", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -499,11 +507,12 @@ def main():
     smp = samplers.DdimSampler(fw)
     x = C.seeded_randn(123 + rank, B, 4, S, S).to(dev)
     fwd_per_step = 2 if has_cls and a.guidance > 0 else 1
-    # DDIM 50-step schedule of config 2: (1000,980) ... (20,0); the bench walks it cyclically
+    # DDIM 50-step schedule of config 2: (1000,980) ... (20,0).  The bench walks it with stride 7 (coprime with 50): any number of
+    # timed steps samples the timesteps uniformly -- the adaptive precision mode's cost depends on t, no other mode's does
     pairs = [(20 * (i + 1), 20 * i) for i in reversed(range(50))]
 
     def step(i, x):
-        t, tp = pairs[i % 50]
+        t, tp = pairs[(7 * i) % 50]
         return smp.sample_once(x, t, tp, classes, False, 0.0, **kw).pred_x_prev
 
     def fence():
@@ -517,6 +526,9 @@ def main():
         xi = x
         for i in range(max(warmup, 2)):   # the first call is eager, the second captures the hipGraph: never timed
             xi = step(i, xi)
+        if getattr(model, "_high_t_precision", None) is not None:   # adaptive mode: BOTH plans are warm before the clock starts
+            for t, tp in ((1000, 980), (1000, 980), (20, 0), (20, 0)):
+                xi = smp.sample_once(xi, t, tp, classes, False, 0.0, **kw).pred_x_prev
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -560,6 +572,13 @@ def main():
         "mfma_roofline_frac_whole_step": round(job_tflops / world / peak, 4),
     }
 
+    if getattr(model, "_high_t_precision", None) is not None:
+        ts = [pairs[(7 * (a.warmup + i)) % 50][0] - 1 for i in range(a.steps)]
+        n_hi = sum(1 for t in ts if t >= model.adaptive_t)
+        result["adaptive"] = {"low_t_mode": model._base_precision, "high_t_mode": model._high_t_precision, "t_threshold": model.adaptive_t,
+                              "timed_steps_in_high_t_mode": n_hi, "timed_steps": a.steps,
+                              "share_over_the_50_step_schedule": round(sum(1 for t, _ in pairs if t - 1 >= model.adaptive_t) / 50.0, 2),
+                              "note": "the kernel table and `roofline` below describe the low-t (base) plan"}
     if rank == 0 and not a.no_kernel_breakdown:
         plan = model.plan(B, stacked=(fwd_per_step == 2))
         prof = plan.profile_eager()
@@ -642,6 +661,13 @@ def main():
         modes[pp] = {"dtype": ARITH[pp], "precision_mode": pp, "value": round(pf, 4), "unit": result["unit"], "steps": psteps,
                      "ms_per_step": round(1e3 * pdt / psteps, 3), "job_tflops": round(ptf, 2),
                      "frac": round(ptf / world / PEAK_TFLOPS[pp], 4)}
+        if getattr(model, "_high_t_precision", None) is not None:   # adaptive: which timesteps the few timed steps sampled
+            ts = [pairs[(7 * (2 + i)) % 50][0] - 1 for i in range(psteps)]
+            modes[pp]["adaptive"] = {"low_t_mode": model._base_precision, "high_t_mode": model._high_t_precision, "t_threshold": model.adaptive_t,
+                                     "timed_steps_in_high_t_mode": sum(1 for t in ts if t >= model.adaptive_t), "timed_steps": psteps,
+                                     "share_over_the_50_step_schedule": round(sum(1 for t, _ in pairs if t - 1 >= model.adaptive_t) / 50.0, 2),
+                                     "status": "opt-in (--precision fp16sa / AdmUnet2d(precision='fp16sa')): not in the headline rule's "
+                                               "speed order until its PMC profiles exist", "note": MODE_NOTE[pp]}
     model.set_precision(a.precision)
     if dev_tab:
         result["parity"] = dict(dev_tab[a.precision], within_tolerance=within_tolerance(dev_tab[a.precision]))

@@ -18,8 +18,14 @@ F32, BF16, F16, BF16X3 = 0, 1, 2, 3   # include/ivid_hip.h IVID_*
 # "fp16s" (round 4): fp16cx + every 1x1 skip_connection in split precision (three MFMA passes: the trunk itself is that
 # convolution's operand) + the stem and the first encoder level as a split-precision island (fp32 storage, bf16 hi + lo operands,
 # three MFMA passes) -- the mode that stays inside 1e-3 of the fp32 reference on clean, smooth inputs at small t too.
-PRECISIONS = {"fp32": F32, "bf16": BF16, "fp16": F16, "bf16x3": BF16X3, "fp16c": F16, "fp16cx": F16, "fp16s": F16}
-COMPENSATED = {"fp16c": 1, "fp16cx": 2, "fp16s": 3}
+PRECISIONS = {"fp32": F32, "bf16": BF16, "fp16": F16, "bf16x3": BF16X3, "fp16c": F16, "fp16cx": F16, "fp16s": F16, "fp16cs": F16,
+              "fp16sa": F16}
+COMPENSATED = {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3}
+# "fp16cs" = fp16s WITHOUT its bf16x3 island (stem + first encoder level): inside the tolerance only when the input carries diffusion
+# noise.  "fp16sa" (adaptive, opt-in) = fp16s, except that a forward whose caller announced a timestep >= ADAPTIVE_T
+# (AdmUnet2d.note_timestep: the samplers know t on the host) runs the fp16cs plan.
+NO_ISLAND = {"fp16cs"}
+ADAPTIVE = {"fp16sa": ("fp16s", "fp16cs")}
 
 
 def esz(dtype):

@@ -77,7 +77,7 @@ class PackedWeights:
     """Weights repacked once into the kernels' layouts: conv [Cout][tap][Cin] in the compute dtype,
     Linear / GroupNorm / bias / embedding tables in fp32, all emb_layers fused into one matrix."""
 
-    def __init__(self, spec: UNetSpec, sd, device, dtype, comp=False):
+    def __init__(self, spec: UNetSpec, sd, device, dtype, comp=False, island=None):
         self.dtype = dtype
         # 1: precision mode fp16c (compensated trunk storage, split stem and head); 2: fp16cx (+ input lo planes);
         # 3: fp16s (+ split-precision 1x1 skip convolutions; stem + first encoder level as a bf16x3 island)
@@ -90,7 +90,12 @@ class PackedWeights:
         # matrix operand of the MFMA kernels: compute dtype, or the hi/lo split form of the bf16x3 mode
         mat_split = lambda w: split_pack(w.contiguous())
         mat = mat_split if dtype == _lib.BF16X3 else (lambda w: w.to(tdt).contiguous())
-        self.island = set(island_stages(spec)) if self.comp >= 3 else set()
+        # island = None: what the level implies (3 -> yes).  False with level 3 = precision mode fp16cs: compensated storage, lo-plane
+        # inputs and split-precision skip convolutions WITHOUT the bf16x3 island (inside the tolerance once the input carries
+        # diffusion noise, t >= 250: the high-t half of the adaptive mode fp16sa, adm.py)
+        self.island_on = (self.comp >= 3) if island is None else bool(island)
+        assert not self.island_on or self.comp >= 3
+        self.island = set(island_stages(spec)) if self.island_on else set()
         isl = {o.prefix for i in self.island for o in spec.stages[i].ops}    # ops whose weights take the bf16x3 layout
 
         def conv3(name, pad_cin=None):
@@ -118,7 +123,7 @@ class PackedWeights:
 
         # stem: the 3x3 patch of the few input channels is ONE K row (k = tap*Cin + c, ivid_stem_im2col), padded to a K-step
         ws = g("input_blocks.0.0.weight").permute(0, 2, 3, 1).reshape(spec.stem_out, -1)   # [Cout, 9*Cin]
-        if self.comp >= 3:   # the stem opens the bf16x3 island: plain im2col row, weights in the hi/lo split layout (K-step 32)
+        if self.island_on:   # the stem opens the bf16x3 island: plain im2col row, weights in the hi/lo split layout (K-step 32)
             self.stem_k = _pad_to(9 * spec.in_channels, 32)
             t["input_blocks.0.0.weight"] = mat_split(torch.nn.functional.pad(ws, (0, self.stem_k - ws.shape[1])))
         elif comp:   # split stem (ivid_stem_im2col_split): K row [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo]

@@ -17,7 +17,7 @@ import torch
 
 from ... import _lib
 from ...utils import AttrDict, default_noise
-from .utils import as_f32, f32, framework_eps, uniform_timestep
+from .utils import announce_timestep, as_f32, f32, framework_eps, uniform_timestep
 
 try:  # progress bars are optional plumbing
     from tqdm import tqdm
@@ -62,6 +62,7 @@ class DdimSampler:
         b, c, h, w = x_t.shape
         assert c == 4, "the fused step kernel is specialised for RGBD (4-channel) samples"
         t_model = torch.full((b,), ti - 1, dtype=torch.int64, device=x_t.device)
+        announce_timestep(self.framework, ti - 1)
         eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
         rgb = rgb_m = dep = dep_m = convex = None
         w_rgb = w_dep = w_con = -1.0

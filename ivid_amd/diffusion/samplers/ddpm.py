@@ -11,7 +11,7 @@ import torch
 
 from ... import _lib
 from ...utils import AttrDict, default_noise
-from .utils import as_f32, f32, framework_eps, uniform_timestep
+from .utils import announce_timestep, as_f32, f32, framework_eps, uniform_timestep
 
 try:
     from tqdm import tqdm
@@ -55,6 +55,7 @@ class DdpmSampler:
         hw = x_t[0].numel() // 4
         assert x_t.shape[1] == 4, "the fused step kernel is specialised for RGBD (4-channel) samples"
         t_model = torch.full((b,), ti, dtype=torch.int64, device=x_t.device)
+        announce_timestep(self.framework, ti)
         eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
         k = self._coef(ti, strength, clip_denoised)
         # drawn every step by the reference, also at t == 0 where it is multiplied by 0 (ddpm.py:128-130)

@@ -27,6 +27,16 @@ def as_f32(t):
     return t.float().contiguous()
 
 
+def announce_timestep(framework, t_model):
+    """Tell the backbone the host-side value of the timestep tensor the next `model_inference` call will carry (the samplers build
+    that tensor from a Python int; the backbone would have to synchronise to read it back): AdmUnet2d.note_timestep, which only the
+    adaptive precision mode looks at.  Other backbones are left alone."""
+    bb = getattr(framework, "backbone", None)
+    bb = getattr(bb, "module", bb)
+    if hasattr(bb, "note_timestep"):
+        bb.note_timestep(t_model)
+
+
 def framework_eps(framework, x_t, t_model, classes, kwargs):
     """-> (eps_cond, eps_uncond | None, strength) for the fused step kernels.  Frameworks of this package expose `eps_branches`
     (both guidance branches out of ONE stacked forward, combined inside the step kernel).  Any other object with the

@@ -82,7 +82,11 @@ FWD_SET_SCENES = (("smooth", dict(seed=0, smooth_color=True, layers=False), 7),
                   ("layers", dict(seed=1, smooth_color=False, layers=True), 416))
 
 
-def fwd_set_inputs(in_channels=4, S=128):
+# timesteps between the set's low-noise rows: where the adaptive precision mode switches plans (AdmUnet2d.note_timestep)
+FWD_SET_T_MID = (50, 100, 150, 350)
+
+
+def fwd_set_inputs(in_channels=4, S=128, ts=None, seed_base=7000):
     """[(key, x_t [1,C,S,S] fp32, t, class)] with x_t = sqrt(abar_t) * x0 + sqrt(1 - abar_t) * n (gaussian_diffusion.py:45-56,
     linear betas, 1000 timesteps), x0 = tests/warp_common.synthetic_rgbd in [-1, 1], n = seeded_randn(7000 + 100*scene + index of t).
     The same recipe runs in tests/golden/make_golden_fwd_set.py (live reference) and on the GPU box."""
@@ -94,8 +98,8 @@ def fwd_set_inputs(in_channels=4, S=128):
         x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
         if in_channels > 4:   # conditional / SR models: the remaining channels carry the clean scene (y, mask-like planes)
             x0 = torch.cat([x0, x0[:, : in_channels - 4]], 1)
-        for ti, t in enumerate(FWD_SET_T):
-            n = seeded_randn(7000 + 100 * si + ti, 1, in_channels, S, S)
+        for ti, t in enumerate(FWD_SET_T if ts is None else ts):
+            n = seeded_randn(seed_base + 100 * si + ti, 1, in_channels, S, S)
             x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
             if in_channels > 4:
                 x[:, 4:] = x0[:, 4:]
@@ -163,6 +167,9 @@ FWD_SETS = {
     "small128": (SMALL128, 3, "small128_fwd_set", lambda: fwd_set_inputs(4, 128), None),
     "largecond128": (LARGE128_COND, 2, "largecond128_fwd_set", fwd_set_inputs_cond, None),
     "sr256": (SR256, 6, "sr256_fwd_set", fwd_set_inputs_sr, SR_CROP),
+    # the same two models between the low-noise rows of their sets (t = 50, 100, 150, 350; noise seeds 7050 + ...)
+    "large128_mid": (LARGE128, 4, "large128_fwd_set_mid", lambda: fwd_set_inputs(4, 128, FWD_SET_T_MID, 7050), None),
+    "small128_mid": (SMALL128, 3, "small128_fwd_set_mid", lambda: fwd_set_inputs(4, 128, FWD_SET_T_MID, 7050), None),
 }
 
 
@@ -175,8 +182,22 @@ def fwd_set_deviation(model, tag, device="cuda"):
     x = torch.cat([i[1] for i in ins]).to(device)
     t = torch.tensor([i[2] for i in ins], device=device)
     rows = {}
-    if args["num_classes"] is not None:
-        cls = torch.tensor([i[3] for i in ins], device=device)
+    has_cls = args["num_classes"] is not None
+    cls = torch.tensor([i[3] for i in ins], device=device) if has_cls else None
+    if getattr(model, "_high_t_precision", None) is not None:
+        # adaptive precision mode: the plan depends on the timestep the caller announces (as the samplers do, one t per call) --
+        # every group of rows with one t is its own announced forward
+        ec = torch.empty(len(ins), args["out_channels"], args["image_size"], args["image_size"]) if has_cls else None
+        eu = torch.empty(len(ins), args["out_channels"], args["image_size"], args["image_size"])
+        for tv in sorted({i[2] for i in ins}):
+            idx = torch.tensor([k for k, i in enumerate(ins) if i[2] == tv])
+            model.note_timestep(tv)
+            if has_cls:
+                a, b = model.forward_cfg(x[idx.to(device)], t[idx.to(device)], cls[idx.to(device)])
+                ec[idx], eu[idx] = a.cpu(), b.cpu()
+            else:
+                eu[idx] = model(x[idx.to(device)], t[idx.to(device)], None).cpu()
+    elif has_cls:
         ec, eu = [v.cpu() for v in model.forward_cfg(x, t, cls)]
     else:
         ec, eu = None, model(x, t, None).cpu()

@@ -1,6 +1,6 @@
 """Reference forwards on the inputs a sampling chain actually feeds the network (round 4; SURVEY.md §8(c): "full forward
 at t in {0, 20, 500, 999}"), generated from the LIVE reference (/root/reference), build container only:
-    python tests/golden/make_golden_fwd_set.py [large] [small]
+    python tests/golden/make_golden_fwd_set.py [large] [small] [largemid] [smallmid]
 x_t = sqrt(abar_t) * x0 + sqrt(1 - abar_t) * n, x0 = two synthetic RGBD scenes (tests/warp_common.synthetic_rgbd), t in
 {0, 20, 250, 500, 750, 999} (tests/common.fwd_set_inputs: the same recipe rebuilds the inputs on the GPU box).  The
 reference's own q-sample is used to make x_t (GaussianDiffusion.diffuse, gaussian_diffusion.py:45-56) and checked against the
@@ -53,19 +53,20 @@ torch.set_num_threads(os.cpu_count())
 
 
 @torch.no_grad()
-def run(name, args, seed, with_classes):
+def run(name, args, seed, with_classes, ts=None, seed_base=7000):
+    ts = C.FWD_SET_T if ts is None else ts
     m = rb.AdmUnet2d(**args).eval()
     sd = C.synth_weights(args, seed)
     m.load_state_dict(sd, strict=True)
     fw = rf.GaussianDiffusion(m, timesteps=1000, beta_schedule="linear")
     arrays, worst, t0 = {}, 0.0, time.time()
-    inputs = C.fwd_set_inputs(args["in_channels"], args["image_size"])
+    inputs = C.fwd_set_inputs(args["in_channels"], args["image_size"], ts, seed_base)
     for si, (tag, kw, _) in enumerate(C.FWD_SET_SCENES):   # the recipe's x_t IS the reference's q-sample
         x0 = torch.from_numpy(WC.synthetic_rgbd(args["image_size"], **kw)).float()
-        for ti, t in enumerate(C.FWD_SET_T):
-            n = C.seeded_randn(7000 + 100 * si + ti, 1, 4, args["image_size"], args["image_size"])
+        for ti, t in enumerate(ts):
+            n = C.seeded_randn(seed_base + 100 * si + ti, 1, 4, args["image_size"], args["image_size"])
             xr = fw.diffuse(x0, torch.tensor([t]), n)
-            assert C.rel_l2(inputs[si * len(C.FWD_SET_T) + ti][1], xr) < 2e-7
+            assert C.rel_l2(inputs[si * len(ts) + ti][1], xr) < 2e-7
     for key, x, t, cls in inputs:
         tt = torch.tensor([t], dtype=torch.long)
         branches = [("c", torch.tensor([cls])), ("u", None)] if with_classes else [("u", None)]
@@ -80,7 +81,7 @@ def run(name, args, seed, with_classes):
     mf = os.path.join(HERE, "manifest.json")
     man = json.load(open(mf))
     man[name] = dict(note=f"{len(arrays) - len(inputs)} reference forwards (fp32) on x_t = q_sample(synthetic RGBD scene, t), "
-                          f"t in {list(C.FWD_SET_T)}, scenes {[s[0] for s in C.FWD_SET_SCENES]}"
+                          f"t in {list(ts)}, scenes {[s[0] for s in C.FWD_SET_SCENES]}"
                           + (", classes [7] / [416] and the null class" if with_classes else ""),
                      oracle_vs_reference=dict(rel_l2_max=worst, ref_seconds=round(time.time() - t0, 1)))
     json.dump(man, open(mf, "w"), indent=1, sort_keys=True)
@@ -92,3 +93,8 @@ if "large" in which:
     run("large128_fwd_set", C.LARGE128, 4, True)
 if "small" in which:
     run("small128_fwd_set", C.SMALL128, 3, False)
+# between the low-noise rows (t = 50, 100, 150, 350): where the adaptive precision mode switches plans
+if "largemid" in which:
+    run("large128_fwd_set_mid", C.LARGE128, 4, True, C.FWD_SET_T_MID, 7050)
+if "smallmid" in which:
+    run("small128_fwd_set_mid", C.SMALL128, 3, False, C.FWD_SET_T_MID, 7050)

@@ -1,0 +1,100 @@
+"""The adaptive precision mode "fp16sa" (opt-in; ivid_amd/diffusion/backbones/adm.py note_timestep): fp16s, except that a forward
+whose caller announced a timestep >= adaptive_t (default 250) runs fp16s WITHOUT its split-precision island ("fp16cs").  The
+island buys its tolerance on nearly clean inputs only; every row of every forward set -- the four BASELINE backbones plus the
+mid-t sets of the large and small models (t = 50, 100, 150, 350) -- is checked here in the mode its timestep selects, against the
+live reference's outputs."""
+import pytest
+import torch
+
+import common as C
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+BAR = 9.5e-4
+
+
+def build(args, seed, precision):
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    m = AdmUnet2d(**args, precision=precision)
+    m.load_state_dict(C.synth_weights(args, seed), strict=True)
+    return m.cuda().eval()
+
+
+def test_the_announced_timestep_selects_the_plan_and_is_consumed_by_one_call():
+    args = C.MINI
+    ma, ms, mc = build(args, 5, "fp16sa"), build(args, 5, "fp16s"), build(args, 5, "fp16cs")
+    T = ma.adaptive_t
+    x = C.seeded_randn(1, 3, 4, 32, 32).cuda()
+    cls = torch.tensor([1, 4, 7]).cuda()
+    for t in (T - 1, T, 999):
+        tt = torch.full((3,), t, dtype=torch.long).cuda()
+        want_s, want_c = ms(x, tt, cls), mc(x, tt, cls)
+        assert not torch.equal(want_s, want_c)
+        assert torch.equal(ma(x, tt, cls), want_s)                       # nobody announced anything: the base mode
+        ma.note_timestep(t)
+        assert torch.equal(ma(x, tt, cls), want_c if t >= T else want_s)
+        assert torch.equal(ma(x, tt, cls), want_s)                       # the announcement was for ONE call
+        ma.note_timestep(t)
+        ec, eu = ma.forward_cfg(x, tt, cls)
+        rc, ru = (mc if t >= T else ms).forward_cfg(x, tt, cls)
+        assert torch.equal(ec, rc) and torch.equal(eu, ru)
+    # a call that fails still consumes its announcement
+    ma.note_timestep(999)
+    with pytest.raises(IndexError):
+        ma(x, torch.full((3,), 999).cuda(), torch.tensor([1, 4, 10 ** 6]).cuda())
+    tt = torch.full((3,), 999, dtype=torch.long).cuda()
+    assert torch.equal(ma(x, tt, cls), ms(x, tt, cls))
+    # the other modes ignore announcements
+    ms.note_timestep(999)
+    assert torch.equal(ms(x, tt, cls), ma(x, tt, cls))
+
+
+def test_a_sampler_chain_in_the_adaptive_mode_is_the_two_modes_spliced_at_the_threshold():
+    from ivid_amd.diffusion import frameworks, samplers
+    args = C.MINI
+    ms_ = {p: build(args, 5, p) for p in ("fp16sa", "fp16s", "fp16cs")}
+    fw = {p: frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1) for p, m in ms_.items()}
+    sm = {p: samplers.DdimSampler(f) for p, f in fw.items()}
+    T = ms_["fp16sa"].adaptive_t
+    cls = torch.tensor([2, 9]).cuda()
+    x_a = x_b = C.seeded_randn(3, 2, 4, 32, 32).cuda() * 0.05           # small: the synthetic-weight chain must stay finite
+    pairs = [(t, t - 100) for t in range(1000, 0, -100)]
+    used = set()
+    for t, tp in pairs:
+        x_a = sm["fp16sa"].sample_once(x_a, t, tp, cls, strength=0.5).pred_x_prev
+        p = "fp16cs" if t - 1 >= T else "fp16s"
+        used.add(p)
+        x_b = sm[p].sample_once(x_b, t, tp, cls, strength=0.5).pred_x_prev
+        assert torch.equal(x_a, x_b), t
+    assert used == {"fp16cs", "fp16s"} and bool(torch.isfinite(x_a).all())
+    # DDPM announces its timestep too
+    fwp = {p: frameworks.GaussianDiffusion(ms_[p], timesteps=1000, beta_schedule="linear") for p in ms_}
+    dp = {p: samplers.DdpmSampler(f) for p, f in fwp.items()}
+    noise = C.seeded_randn(4, 2, 4, 32, 32).cuda()
+    xa = dp["fp16sa"].sample_once(x_a, 600, noise_fn=lambda s: noise).pred_x_prev
+    xc = dp["fp16cs"].sample_once(x_a, 600, noise_fn=lambda s: noise).pred_x_prev
+    assert torch.equal(xa, xc)
+
+
+@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid"])
+def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
+    args, seed, gname, make, _crop = C.FWD_SETS[tag]
+    g = C.load_golden(gname)
+    for key, x, _, _ in make():   # the seeded recipe rebuilds the generator's inputs
+        assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
+    m = build(args, seed, "fp16sa")
+    out = {}
+    for prec in ("fp16sa", "fp16s", "fp16cs"):
+        m.set_precision(prec)
+        rows = C.fwd_set_deviation(m, tag)
+        worst = max(rows, key=rows.get)
+        out[prec] = rows
+        G.report(f"fwd_set/{tag}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), **rows)
+    T = m.adaptive_t
+    tof = lambda key: int(key.split("_t")[1].split("_")[0])
+    print(f"forward set {tag}:", {p: "%.3e" % max(r.values()) for p, r in out.items()},
+          "| fp16cs at t >= %d: %.3e" % (T, max([v for k, v in out["fp16cs"].items() if tof(k) >= T], default=0.0)))
+    for key, v in out["fp16sa"].items():                                   # the adaptive mode IS the splice, row by row
+        assert v == out["fp16cs" if tof(key) >= T else "fp16s"][key], key
+    assert max(out["fp16sa"].values()) < BAR, (tag, out["fp16sa"])
+    assert max(out["fp16s"].values()) < BAR, (tag, out["fp16s"])           # the headline mode on the mid-t rows as well

@@ -160,11 +160,46 @@ def test_unsupported_attention_geometry_is_refused_at_construction():
     AdmUnet2d(**C.MINI)
 
 
+def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
+    """AdmUnet2d.note_timestep (host logic): only "fp16sa" has a high-t mode; an announcement selects it from adaptive_t upwards, is
+    consumed by ONE query, and IVID_ADAPTIVE_T moves the threshold."""
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    m = AdmUnet2d(**C.MINI, precision="fp16sa")
+    assert (m._base_precision, m._high_t_precision, m.adaptive_t) == ("fp16s", "fp16cs", 250)
+    assert m._take_high_t() is False
+    for t, want in ((249, False), (250, True), (999, True), (0, False)):
+        m.note_timestep(t)
+        assert m._take_high_t() is want and m._take_high_t() is False
+    m.set_precision("fp16s")
+    m.note_timestep(999)
+    assert m._high_t_precision is None and m._take_high_t() is False
+    os.environ["IVID_ADAPTIVE_T"] = "600"
+    try:
+        m.set_precision("fp16sa")
+        m.note_timestep(599)
+        assert m._take_high_t() is False
+        m.note_timestep(600)
+        assert m._take_high_t() is True
+    finally:
+        del os.environ["IVID_ADAPTIVE_T"]
+    # the samplers announce through the framework: backbones without note_timestep are left alone
+    from ivid_amd.diffusion.samplers.utils import announce_timestep
+
+    class FW:
+        backbone = m
+    m.set_precision("fp16sa")
+    announce_timestep(FW, 700)
+    assert m._take_high_t() is True
+    announce_timestep(type("X", (), {"backbone": object()}), 5)
+    announce_timestep(object(), 5)
+
+
 def test_precision_names_and_reference_fp16_api():
     from ivid_amd import _lib
     from ivid_amd.diffusion.backbones import AdmUnet2d
-    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2}
-    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3}
+    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2}
+    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3}
+    assert _lib.NO_ISLAND == {"fp16cs"} and _lib.ADAPTIVE == {"fp16sa": ("fp16s", "fp16cs")}
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
@@ -338,3 +373,15 @@ def test_bench_flop_accounting_adds_up_to_the_reference_count(monkeypatch):
     launched = sum(f["flop"] for f in fam.values())
     assert abs((launched + shared) / ref - 1.0) < 5e-3, (launched + shared) / ref
     assert "ivid_f32_to_hilo" not in other
+    # fp16cs (the high-t half of the adaptive mode): the same plan WITHOUT the island -- no bf16x3 launch, no fp16 twins, the stem
+    # in its split 16-bit form, the split-precision skip convolutions all there
+    plc = P.UNetPlan(spec, P.PackedWeights(spec, sd, "meta", _lib.F16, comp=3, island=False), "meta", bsrc, True)
+    cn = [n for _fn, n, _a in plc.launches]
+    assert cn.count("ivid_conv3x3_gn_o16") == 0 and cn.count("ivid_conv2d_o16") == 0 and cn.count("ivid_f32_to_hilo") == 0
+    assert cn.count("ivid_stem_im2col_split") == 1 and cn.count("ivid_conv3x3_gn_skip_s") == names.count("ivid_conv3x3_gn_skip_s")
+    dts = {a[0] for _fn, n, a in plc.launches if n in ("ivid_conv3x3_gn_skip_c", "ivid_conv3x3_gn_skip_s", "ivid_conv2d_c", "ivid_conv2d")}
+    assert dts == {_lib.F32, _lib.F16}, dts            # fp32: the embedding MLP (nn.Linear is never cast, backbones/utils.py:6-13)
+    profc = [(n, a, 1.0) for _fn, n, a in plc.launches]
+    famc, _ = bench.kernel_table(profc, "fp16cs")
+    launched_c = sum(f["flop"] for f in famc.values())
+    assert abs((launched_c + shared) / ref - 1.0) < 5e-3

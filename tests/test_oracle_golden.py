@@ -146,6 +146,29 @@ def test_oracle_reproduces_the_representative_forward_set_small_and_large_rows()
             assert C.rel_l2(adm_oracle.unet_forward(sd, args, x, tt, None), g[key + "_u"]) < 1e-5, key
 
 
+def test_oracle_reproduces_the_mid_t_forward_sets():
+    """tests/golden/{large,small}128_fwd_set_mid.npz (make_golden_fwd_set.py largemid smallmid): the rows between the low-noise
+    timesteps of the main sets (t = 50, 100, 150, 350), where the adaptive precision mode switches plans -- recipe and oracle
+    against the live reference's outputs (all 8 rows of the small set, the t = 50 smooth row of the large one)."""
+    import json
+    import os
+    man = json.load(open(os.path.join(C.GOLDEN, "manifest.json")))
+    for gname, args, seed, keep in (("small128_fwd_set_mid", C.SMALL128, 3, None), ("large128_fwd_set_mid", C.LARGE128, 4, ("smooth_t50",))):
+        assert man[gname]["oracle_vs_reference"]["rel_l2_max"] == 0.0
+        g = C.load_golden(gname)
+        sd = C.synth_weights(args, seed)
+        ins = C.FWD_SETS[gname.replace("_fwd_set", "")][3]()
+        assert [t for _, _, t, _ in ins] == list(C.FWD_SET_T_MID) * 2
+        for key, x, t, cls in ins:
+            assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
+            if keep is not None and key not in keep:
+                continue
+            tt = torch.tensor([t])
+            if args["num_classes"] is not None:
+                assert C.rel_l2(adm_oracle.unet_forward(sd, args, x, tt, torch.tensor([cls])), g[key + "_c"]) < 1e-5, key
+            assert C.rel_l2(adm_oracle.unet_forward(sd, args, x, tt, None), g[key + "_u"]) < 1e-5, key
+
+
 def test_teacher_forced_steps_golden_is_consistent_with_the_chain_golden():
     """large128_ddim50_cfg_steps.npz records what the reference's framework saw at sample_once calls 1, 10, 25, 49 of the config-2
     chain: the timesteps must be those of the 50-step DDIM schedule (ddim.py:157: t - 1 of (1000 - 20 k)) and the oracle's guided

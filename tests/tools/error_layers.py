@@ -131,13 +131,14 @@ def main():
     ap.add_argument("--extra", default="", help="extra combos on top of cx+skip: 'name=K@prefix,K@prefix;name=...' -- kind K (W / A) is kept "
                     "EXACT at every site whose name starts with prefix (e.g. W@input_blocks.2.0.,A@input_blocks.1.0.in_layers)")
     ap.add_argument("--only-extra", action="store_true", help="run the --extra combos only")
+    ap.add_argument("--mid", action="store_true", help="the rows of the mid-t sets (tests/common.FWD_SET_T_MID) instead of the main set")
     a = ap.parse_args()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     args, seed = (C.LARGE128, 4) if a.model == "large" else (C.SMALL128, 3)
     sd = {k: v.float().to(dev) for k, v in C.synth_weights(args, seed).items()}
-    ins = C.fwd_set_inputs(args["in_channels"], args["image_size"])
+    ins = C.fwd_set_inputs(args["in_channels"], args["image_size"], *((C.FWD_SET_T_MID, 7050) if a.mid else ()))
     has_cls = args.get("num_classes") is not None
     xs, ts, cs, names = [], [], [], []
     for key, x, t, cls in ins:
