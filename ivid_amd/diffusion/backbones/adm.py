@@ -236,11 +236,14 @@ class AdmUnet2d(nn.Module):
         self._plans[key] = p
         return p
 
-    def export_engine(self, batch, stacked=False, path=None):
+    def export_engine(self, batch, stacked=False, path=None, high_t=False):
         """Freeze the launch plan of one (batch, stacked-CFG) shape -- in the model's current precision mode, with its repacked
         weights -- into an engine file (bytes; written to `path` if given) that `ivid_unet_load` runs WITHOUT Python
-        (include/ivid_hip.h; examples/unet_engine_host.c; diffusion/backbones/engine.py for the layout)."""
-        blob = self.plan(batch, stacked).export_engine()
+        (include/ivid_hip.h; examples/unet_engine_host.c; diffusion/backbones/engine.py for the layout).  `high_t`: the adaptive
+        mode's plan for announced timesteps >= adaptive_t (a host that samples from C keeps both engines and picks per step)."""
+        if high_t and self._high_t_precision is None:
+            raise ValueError(f"precision mode {self.precision!r} has no high-t plan (only the adaptive mode 'fp16sa' does)")
+        blob = self.plan(batch, stacked, high_t).export_engine()
         if path is not None:
             with open(path, "wb") as f:
                 f.write(blob)
