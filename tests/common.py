@@ -125,7 +125,10 @@ def inpaint_cond_inputs(x, y, mask, mask_rgb, seed):
     return torch.cat([x, mask_rgb, y_rgb, y_d, mask], dim=1)
 
 
-def fwd_set_inputs_cond(S=128):
+FWD_SET_T_MID_MORE = (100, 250, 350)     # the conditional / SR models around the adaptive mode's threshold
+
+
+def fwd_set_inputs_cond(S=128, ts=None, seed_base=7500, fill_base=9000):
     """[(key, 10-channel model input [1,10,S,S], t, class)]: x_t = q_sample(scene, t) as in fwd_set_inputs, conditioned on the scene
     itself seen through the visibility masks of the scene fixture (sample_all_scene_ref.npz: 88 % coverage)."""
     import warp_common as WC
@@ -135,14 +138,14 @@ def fwd_set_inputs_cond(S=128):
     abar, out = _abar(), []
     for si, (tag, kw, cls) in enumerate(FWD_SET_SCENES):
         x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
-        for ti, t in enumerate(FWD_SET_T_MORE):
-            n = seeded_randn(7500 + 100 * si + ti, 1, 4, S, S)
+        for ti, t in enumerate(FWD_SET_T_MORE if ts is None else ts):
+            n = seeded_randn(seed_base + 100 * si + ti, 1, 4, S, S)
             x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
-            out.append((f"{tag}_t{t}", inpaint_cond_inputs(x, x0, mask, mask_rgb, 9000 + 10 * si + ti).contiguous(), t, cls))
+            out.append((f"{tag}_t{t}", inpaint_cond_inputs(x, x0, mask, mask_rgb, fill_base + 10 * si + ti).contiguous(), t, cls))
     return out
 
 
-def fwd_set_inputs_sr(S=256):
+def fwd_set_inputs_sr(S=256, ts=None, seed_base=7800):
     """[(key, 8-channel model input [1,8,S,S], t, class)]: x_t = q_sample(scene at S x S, t), conditioned on the bilinear upsample of
     the 2x2-average-pooled scene (SuperResCFG.make_cond_inputs, sr_cfg.py:23-36)."""
     import warp_common as WC
@@ -151,8 +154,8 @@ def fwd_set_inputs_sr(S=256):
         x0 = torch.from_numpy(WC.synthetic_rgbd(S, **kw)).float()
         low = torch.nn.functional.avg_pool2d(x0, 2).clamp(-1, 1)
         up = torch.nn.functional.interpolate(low, scale_factor=2, mode="bilinear", align_corners=False)
-        for ti, t in enumerate(FWD_SET_T_MORE):
-            n = seeded_randn(7800 + 100 * si + ti, 1, 4, S, S)
+        for ti, t in enumerate(FWD_SET_T_MORE if ts is None else ts):
+            n = seeded_randn(seed_base + 100 * si + ti, 1, 4, S, S)
             x = float(np.sqrt(abar[t])) * x0 + float(np.sqrt(1.0 - abar[t])) * n
             out.append((f"{tag}_t{t}", torch.cat([x, up], 1).contiguous(), t, cls))
     return out
@@ -170,6 +173,8 @@ FWD_SETS = {
     # the same two models between the low-noise rows of their sets (t = 50, 100, 150, 350; noise seeds 7050 + ...)
     "large128_mid": (LARGE128, 4, "large128_fwd_set_mid", lambda: fwd_set_inputs(4, 128, FWD_SET_T_MID, 7050), None),
     "small128_mid": (SMALL128, 3, "small128_fwd_set_mid", lambda: fwd_set_inputs(4, 128, FWD_SET_T_MID, 7050), None),
+    "largecond128_mid": (LARGE128_COND, 2, "largecond128_fwd_set_mid", lambda: fwd_set_inputs_cond(128, FWD_SET_T_MID_MORE, 7550, 9050), None),
+    "sr256_mid": (SR256, 6, "sr256_fwd_set_mid", lambda: fwd_set_inputs_sr(256, FWD_SET_T_MID_MORE, 7850), SR_CROP),
 }
 
 

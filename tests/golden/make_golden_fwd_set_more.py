@@ -1,5 +1,5 @@
 """Representative forward sets of the CONDITIONAL and the SUPER-RESOLUTION model (round 4), from the LIVE reference
-(/root/reference), build container only:   python tests/golden/make_golden_fwd_set_more.py [cond] [sr]
+(/root/reference), build container only:   python tests/golden/make_golden_fwd_set_more.py [cond] [sr] [condmid] [srmid]
   largecond128_fwd_set.npz  rgbd_imagenet_adm_128_large_cond backbone (10 input channels, fp32): x_t = q_sample(scene, t) conditioned,
                             through the reference's own InpaintCFG.make_cond_inputs (inpaint_cfg.py:24-49), on the scene seen through the
                             visibility masks of the scene fixture; t in {0, 20, 500, 999}, 2 scenes, both guidance branches (16 forwards)
@@ -54,6 +54,9 @@ man_path = os.path.join(HERE, "manifest.json")
 man = json.load(open(man_path))
 
 
+TS, FILL_BASE = C.FWD_SET_T_MORE, 9000     # what check_cond needs to re-draw the recipe's fills (set per run below)
+
+
 @torch.no_grad()
 def run(name, args, seed, inputs, check_input, crop):
     m = rb.AdmUnet2d(**args).eval()
@@ -72,7 +75,7 @@ def run(name, args, seed, inputs, check_input, crop):
         print(name, key, f"|eps| rms {float(ref.pow(2).mean().sqrt()):.3f}", flush=True)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
     man[name] = dict(note=f"{len(arrays) - len(inputs)} reference forwards (fp32) of {name.split('_')[0]} on conditioned q-samples of two synthetic "
-                          f"RGBD scenes, t in {list(C.FWD_SET_T_MORE)}, both guidance branches" + (", 128 x 128 centre window stored" if crop else ""),
+                          f"RGBD scenes, t in {list(TS)}, both guidance branches" + (", 128 x 128 centre window stored" if crop else ""),
                      oracle_vs_reference=dict(rel_l2_max=worst, ref_seconds=round(time.time() - t0, 1)))
     print(name, man[name], flush=True)
 
@@ -80,12 +83,12 @@ def run(name, args, seed, inputs, check_input, crop):
 def check_cond(m, key, x, t):
     """the recipe's 10-channel input IS what the reference's InpaintCFG.make_cond_inputs builds (same generator draws)"""
     fw = rf.InpaintCFG(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
-    si = [s[0] for s in C.FWD_SET_SCENES].index(key.split("_t")[0]); ti = C.FWD_SET_T_MORE.index(t)
+    si = [s[0] for s in C.FWD_SET_SCENES].index(key.split("_t")[0]); ti = list(TS).index(t)
     sc = C.load_golden("sample_all_scene_ref")
     mask = torch.from_numpy(sc["cond_mask"][:1].astype(np.float32)).permute(0, 3, 1, 2)
     mask_rgb = torch.from_numpy(sc["cond_mask_rgb"][:1].astype(np.float32)).permute(0, 3, 1, 2)
     x0 = torch.from_numpy(WC.synthetic_rgbd(128, **C.FWD_SET_SCENES[si][1])).float()
-    torch.manual_seed(9000 + 10 * si + ti)
+    torch.manual_seed(FILL_BASE + 10 * si + ti)
     ref_in = fw.make_cond_inputs(x[:, :4], x0, mask, mask_rgb=mask_rgb)
     assert torch.equal(ref_in, x), key
 
@@ -103,4 +106,10 @@ if "cond" in which:
     run("largecond128_fwd_set", C.LARGE128_COND, 2, C.fwd_set_inputs_cond(), check_cond, None)
 if "sr" in which:
     run("sr256_fwd_set", C.SR256, 6, C.fwd_set_inputs_sr(), check_sr, C.SR_CROP)
+# around the adaptive precision mode's threshold (t = 100, 250, 350)
+TS, FILL_BASE = C.FWD_SET_T_MID_MORE, 9050
+if "condmid" in which:
+    run("largecond128_fwd_set_mid", C.LARGE128_COND, 2, C.FWD_SETS["largecond128_mid"][3](), check_cond, None)
+if "srmid" in which:
+    run("sr256_fwd_set_mid", C.SR256, 6, C.FWD_SETS["sr256_mid"][3](), check_sr, C.SR_CROP)
 json.dump(man, open(man_path, "w"), indent=1, sort_keys=True)

@@ -2,7 +2,7 @@
 whose caller announced a timestep >= adaptive_t (default 250) runs fp16s WITHOUT its split-precision island ("fp16cs").  The
 island buys its tolerance on nearly clean inputs only; every row of every forward set -- the four BASELINE backbones plus the
 mid-t sets of the large and small models (t = 50, 100, 150, 350) -- is checked here in the mode its timestep selects, against the
-live reference's outputs."""
+live reference's outputs (the conditional and SR models have mid-t sets too: t = 100, 250, 350)."""
 import pytest
 import torch
 
@@ -76,7 +76,7 @@ def test_a_sampler_chain_in_the_adaptive_mode_is_the_two_modes_spliced_at_the_th
     assert torch.equal(xa, xc)
 
 
-@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid"])
+@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid", "largecond128_mid", "sr256_mid"])
 def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
     args, seed, gname, make, _crop = C.FWD_SETS[tag]
     g = C.load_golden(gname)
