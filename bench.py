@@ -388,6 +388,22 @@ def kernel_table(prof, precision):
     return fam, other
 
 
+def merge_kernel_tables(lo, hi, share_hi):
+    """Schedule-weighted kernel table of the adaptive precision mode: `lo` / `hi` = (fam, other) of one eager forward of the low-t /
+    high-t plan, share_hi = the share of the schedule's steps that run the high-t plan.  Every additive field (ms, launches, FLOPs,
+    bytes) is weighted, so ms / n is the average launch duration over the launches the schedule issues."""
+    w = (1.0 - share_hi, share_hi)
+    fam, other = {}, {}
+    for wk, (f_, o_) in zip(w, (lo, hi)):
+        for k, f in f_.items():
+            g = fam.setdefault(k, dict(ms=0.0, n=0.0, flop=0.0, byt=0.0))
+            for fld in g:
+                g[fld] += wk * f[fld]
+        for k, v in o_.items():
+            other[k] = other.get(k, 0.0) + wk * v
+    return fam, other
+
+
 def roofline_entry(kernel, f, peak_tf, total_ms, batch_n):
     """One `roofline` object.  MFMA kernels: algorithmic TFLOP/s vs the dense peak.  The 4-channel output head is bound by
     its input stream: algorithmic GB/s vs the HBM peak."""
@@ -399,7 +415,7 @@ def roofline_entry(kernel, f, peak_tf, total_ms, batch_n):
         ach = f["flop"] / (f["ms"] * 1e-3) / 1e12
         e = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
              "frac": round(ach / peak_tf, 4)}
-    e.update({"traffic": None, "launches_per_forward": f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 4),
+    e.update({"traffic": None, "launches_per_forward": round(f["n"], 2) if isinstance(f["n"], float) else f["n"], "avg_launch_ms": round(f["ms"] / f["n"], 4),
               "algorithmic_gflop_per_launch_avg": round(f["flop"] / f["n"] / 1e9, 2),
               "algorithmic_bytes_per_launch_avg": round(f["byt"] / f["n"], 0),
               "share_of_forward_time": round(f["ms"] / total_ms, 4), "forward_batch": batch_n})
@@ -578,11 +594,17 @@ def main():
         result["adaptive"] = {"low_t_mode": model._base_precision, "high_t_mode": model._high_t_precision, "t_threshold": model.adaptive_t,
                               "timed_steps_in_high_t_mode": n_hi, "timed_steps": a.steps,
                               "share_over_the_50_step_schedule": round(sum(1 for t, _ in pairs if t - 1 >= model.adaptive_t) / 50.0, 2),
-                              "note": "the kernel table and `roofline` below describe the low-t (base) plan"}
+                              "note": "no kernel table in this run"}
     if rank == 0 and not a.no_kernel_breakdown:
         plan = model.plan(B, stacked=(fwd_per_step == 2))
         prof = plan.profile_eager()
         fam, other = kernel_table(prof, a.precision)
+        if "adaptive" in result:   # both plans, weighted by the schedule's share of high-t steps
+            share = result["adaptive"]["share_over_the_50_step_schedule"]
+            prof_hi = model.plan(B, stacked=(fwd_per_step == 2), high_t=True).profile_eager()
+            fam, other = merge_kernel_tables((fam, other), kernel_table(prof_hi, a.precision), share)
+            result["adaptive"]["note"] = ("the kernel table and `roofline` are schedule-weighted over both plans (%.2f high-t); the "
+                                          "flop_accounting block describes the low-t plan" % share)
         total_ms = sum(f["ms"] for f in fam.values()) + sum(other.values())
         order = sorted(fam, key=lambda k: -fam[k]["ms"])
         entries = [roofline_entry(k, fam[k], peak, total_ms, plan.n) for k in order]

@@ -385,3 +385,18 @@ def test_bench_flop_accounting_adds_up_to_the_reference_count(monkeypatch):
     famc, _ = bench.kernel_table(profc, "fp16cs")
     launched_c = sum(f["flop"] for f in famc.values())
     assert abs((launched_c + shared) / ref - 1.0) < 5e-3
+
+
+def test_bench_merges_the_adaptive_modes_two_kernel_tables_by_schedule_share():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(C.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lo = ({"conv3x3_fused_kernel": dict(ms=70.0, n=35, flop=7e13, byt=1e11), "attn_kernel": dict(ms=2.0, n=16, flop=1e12, byt=1e9)}, {"ivid_gn_apply": 3.0})
+    hi = ({"conv3x3_fused_kernel": dict(ms=60.0, n=35, flop=7e13, byt=9e10), "attn_kernel": dict(ms=2.0, n=16, flop=1e12, byt=1e9)}, {"ivid_gn_apply": 3.0, "ivid_copy": 1.0})
+    fam, other = bench.merge_kernel_tables(lo, hi, 0.76)
+    f = fam["conv3x3_fused_kernel"]
+    assert abs(f["ms"] - (0.24 * 70 + 0.76 * 60)) < 1e-9 and abs(f["n"] - 35) < 1e-9 and abs(f["flop"] - 7e13) < 1
+    assert abs(other["ivid_gn_apply"] - 3.0) < 1e-9 and abs(other["ivid_copy"] - 0.76) < 1e-9
+    e = bench.roofline_entry("conv3x3_fused_kernel", f, 2500.0, 70.0, 128)
+    assert e["launches_per_forward"] == 35.0 and abs(e["avg_launch_ms"] - round(f["ms"] / 35, 4)) < 1e-9
