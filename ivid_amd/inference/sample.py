@@ -162,14 +162,16 @@ def main(argv=None):
     p.add_argument("--atol", type=float, default=0.03)
     p.add_argument("--rtol", type=float, default=0.03)
     p.add_argument("--erode_rgb", type=int, default=3)
-    p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 | fp16cx | fp16c (fp16 MFMA, compensated trunk: within 1e-3 of fp32) | fp16 | bf16; default: fp16c if the config says use_fp16 else fp32")
+    p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 | fp16s (fp16 MFMA, compensated trunk, trunk-critical layers in split precision: within 1e-3 of fp32 on "
+                        "every input) | fp16sa (fp16s without its first-level island at timesteps >= 250: +8 %%) | fp16cx | fp16c | fp16 | bf16; "
+                        "default: fp16s if the config says use_fp16 else fp32")
     # 128 -> 256 super-resolution of every generated view (BASELINE config 5).  Not in the reference CLI: the reference ships
     # the SR model and SuperResCFG but no inference driver for them (only SuperResTrainer.sample, trainers/superres.py:97-134)
     p.add_argument("--config_sr", type=str, default=None, help="e.g. configs/rgbd_imagenet_adm_256_128_small_sr.json")
     p.add_argument("--ckpt_sr", type=str, default=None)
     p.add_argument("--steps_sr", type=int, default=50)
     p.add_argument("--guidance_sr", type=float, default=3.0)
-    p.add_argument("--batchsize_sr", type=int, default=27, help="views per SR batch (27 = a whole 3x9 viewset: +3.5 % per view over 16 + 11)")
+    p.add_argument("--batchsize_sr", type=int, default=27, help="views per SR batch (27 = a whole 3x9 viewset: +3.5 %% per view over 16 + 11)")
     opt = p.parse_args(argv)
     cfg = AttrDict(vars(opt))
     with open(opt.config_uncond) as f:

@@ -400,3 +400,14 @@ def test_bench_merges_the_adaptive_modes_two_kernel_tables_by_schedule_share():
     assert abs(other["ivid_gn_apply"] - 3.0) < 1e-9 and abs(other["ivid_copy"] - 0.76) < 1e-9
     e = bench.roofline_entry("conv3x3_fused_kernel", f, 2500.0, 70.0, 128)
     assert e["launches_per_forward"] == 35.0 and abs(e["avg_launch_ms"] - round(f["ms"] / 35, 4)) < 1e-9
+
+
+@pytest.mark.parametrize("mod", ["ivid_amd.inference.sample", "ivid_amd.inference.render"])
+def test_command_line_help_renders(mod):
+    """`--help` of the two CLIs (README: `python -m ivid_amd.inference.sample --help`): argparse %-formats every help string."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", mod, "--help"], capture_output=True, text=True, cwd=C.ROOT, timeout=300)
+    assert r.returncode == 0 and "usage:" in r.stdout, r.stderr[-400:]
+    if mod.endswith("sample"):
+        assert "--precision" in r.stdout and "fp16s" in r.stdout
