@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--extra", default="", help="extra combos on top of cx+skip: 'name=K@prefix,K@prefix;name=...' -- kind K (W / A) is kept "
                     "EXACT at every site whose name starts with prefix (e.g. W@input_blocks.2.0.,A@input_blocks.1.0.in_layers)")
     ap.add_argument("--only-extra", action="store_true", help="run the --extra combos only")
+    ap.add_argument("--extra-base", default="WAQ", help="rounding classes of the --extra combos' base mode: WAQ = fp16cx, WAHFQ = fp16c")
     ap.add_argument("--mid", action="store_true", help="the rows of the mid-t sets (tests/common.FWD_SET_T_MID) instead of the main set")
     a = ap.parse_args()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
@@ -178,7 +179,7 @@ def main():
     for spec in filter(None, a.extra.split(";")):
         name, items = spec.split("=", 1)
         fixes = [tuple(it.split("@", 1)) for it in items.split(",")]
-        combos[name] = (lambda fx: lambda k, s: k in "WAQ" and not skip(s) and not any(k == kk and s.startswith(pp) for kk, pp in fx))(fixes)
+        combos[name] = (lambda fx: lambda k, s: k in a.extra_base and not skip(s) and not any(k == kk and s.startswith(pp) for kk, pp in fx))(fixes)
     for name, pred in combos.items():
         res["combos"][name] = rows_rel(forward(sd, args, x, t, cl, Sites(pred)), ref)
         print(name, f"max {max(res['combos'][name]):.3e}", flush=True)
