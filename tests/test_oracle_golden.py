@@ -149,16 +149,19 @@ def test_oracle_reproduces_the_representative_forward_set_small_and_large_rows()
 def test_oracle_reproduces_the_mid_t_forward_sets():
     """tests/golden/{large,small}128_fwd_set_mid.npz (make_golden_fwd_set.py largemid smallmid): the rows between the low-noise
     timesteps of the main sets (t = 50, 100, 150, 350), where the adaptive precision mode switches plans -- recipe and oracle
-    against the live reference's outputs (all 8 rows of the small set, the t = 50 smooth row of the large one)."""
+    against the live reference's outputs (all 8 rows of the small set, the t = 50 smooth row of the large one, the t = 250 smooth row
+    of the conditional model's set -- its 10-channel input re-drawn by the recipe of InpaintCFG.make_cond_inputs)."""
     import json
     import os
     man = json.load(open(os.path.join(C.GOLDEN, "manifest.json")))
-    for gname, args, seed, keep in (("small128_fwd_set_mid", C.SMALL128, 3, None), ("large128_fwd_set_mid", C.LARGE128, 4, ("smooth_t50",))):
+    assert man["sr256_fwd_set_mid"]["oracle_vs_reference"]["rel_l2_max"] == 0.0      # checked by the generator (a 256^2 forward: 15 s each)
+    for gname, args, seed, keep in (("small128_fwd_set_mid", C.SMALL128, 3, None), ("large128_fwd_set_mid", C.LARGE128, 4, ("smooth_t50",)),
+                                    ("largecond128_fwd_set_mid", C.LARGE128_COND, 2, ("smooth_t250",))):
         assert man[gname]["oracle_vs_reference"]["rel_l2_max"] == 0.0
         g = C.load_golden(gname)
         sd = C.synth_weights(args, seed)
         ins = C.FWD_SETS[gname.replace("_fwd_set", "")][3]()
-        assert [t for _, _, t, _ in ins] == list(C.FWD_SET_T_MID) * 2
+        assert [t for _, _, t, _ in ins] == list(C.FWD_SET_T_MID_MORE if "cond" in gname else C.FWD_SET_T_MID) * 2
         for key, x, t, cls in ins:
             assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
             if keep is not None and key not in keep:
