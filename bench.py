@@ -277,13 +277,20 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+def _profile_files(suffix):
+    """profiles/r<NN>_<suffix>, the newest round first."""
+    import glob
+    import re
+    hits = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)) if re.match(r"r\d+_" + re.escape(suffix) + "$", os.path.basename(p))]
+    return [os.path.relpath(p, ROOT) for p in sorted(hits, key=lambda p: int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)), reverse=True)]
+
+
 def cached_pmc_traffic(precision):
     """HBM bytes per launch and kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
     over this very command with --precision <mode>; scripts/gpu_pmc_bench.sh -> profiles/r03_pmc_traffic_<mode>.json, gfx950
     correction 2*FETCH + WRITE as MI355X_MICROARCH.md prescribes).  Collected in its own rocprofv3 invocation, NOT in the timed
     run; `csrc_sha` says whether the kernels are still the ones that were profiled."""
-    for rnd in ("r04", "r03"):
-        rel = "profiles/%s_pmc_traffic_%s.json" % (rnd, precision)
+    for rel in _profile_files("pmc_traffic_%s.json" % precision):
         try:
             d = json.load(open(os.path.join(ROOT, rel)))
             return ({k: round(float(v), 0) for k, v in d["per_kernel_hbm_bytes_per_launch"].items()},
@@ -299,10 +306,14 @@ def cached_pmc_mfma(precision):
     mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = the share of all MFMA-pipe cycles that were
     busy while the kernel ran, at the effective clock eff_clock_ghz the chip held (power-limited: < the 2.4 GHz of the nominal
     peak); instantiations of one kernel are merged (their counters add)."""
-    rel = "profiles/r04_pmc_mfma_%s.json" % precision
-    try:
-        d = json.load(open(os.path.join(ROOT, rel)))
-    except Exception:
+    d = rel = None
+    for rel in _profile_files("pmc_mfma_%s.json" % precision):
+        try:
+            d = json.load(open(os.path.join(ROOT, rel)))
+            break
+        except Exception:
+            continue
+    if d is None:
         return {}, None
     out = {}
     for fam in ("conv3x3_fused", "conv_igemm", "attn_kernel", "conv3x3_out"):
