@@ -76,8 +76,14 @@ int ivid_event_destroy(void* ev);
 #define IVID_OP_GN_PARTIAL_C 24   /* ivid_gn_partial_c */
 #define IVID_OP_CONV2D_O16 25     /* ivid_conv2d_o16 */
 #define IVID_OP_LAST 25
+/* Version of the op-code table + the argument lists behind it: bumped whenever an entry point that can appear in a launch
+ * program changes its signature or a code is added.  Engine files carry it; ivid_unet_load refuses any other value. */
+#define IVID_ENGINE_ABI 5
 int ivid_program_create(void** handle_out);
+/* refuses an unknown op code and an `nargs` that is not the argument count of the op's entry point */
 int ivid_program_add(void* handle, int op, const void* args, int nargs);
+/* number of arguments (without the stream) of the entry point behind an op code; -1 for an unknown code */
+int ivid_program_op_arity(int op);
 int ivid_program_num_ops(void* handle);
 /* Replay on `stream`: use_graph = 0 always eager; else run 1 eager (sets kernel attributes), run 2 captures a hipGraph,
  * later runs are one hipGraphLaunch (the stream must not be the legacy default stream). */

@@ -13,7 +13,20 @@
 namespace {
 
 union Slot { long long i; double f; };
-struct Op { int code; int nargs; Slot a[32]; };
+struct Op { int code = 0; int nargs = 0; Slot a[32] = {}; };
+
+// Arguments (without the trailing stream) of the entry point behind every op code, index = IVID_OP_*: run_op reads fixed slots,
+// so a launch record whose nargs disagrees -- a truncated engine file, or one written against other signatures -- is refused
+// before anything is dispatched (ivid_program_add, ivid_unet_load).  tests/test_host_logic.py holds this table against the
+// ctypes signatures of ivid_amd/_lib.py.
+constexpr int kArity[IVID_OP_LAST + 1] = {
+    -1,
+    /* 1 CONV2D */ 18, /* 2 CONV3X3_GN */ 17, /* 3 CONV3X3_GN_SKIP */ 22, /* 4 CONV3X3_GN_OUT */ 11, /* 5 GN_PARTIAL */ 8,
+    /* 6 GN_FINALIZE */ 13, /* 7 GN_FINALIZE2 */ 16, /* 8 GN_APPLY */ 12, /* 9 ATTENTION */ 6, /* 10 EMBED_INPUTS */ 11,
+    /* 11 SILU_F32 */ 3, /* 12 STEM_IM2COL */ 9, /* 13 CONV3X3_UP */ 14, /* 14 COPY */ 3, /* 15 CONV2D_C */ 20,
+    /* 16 CONV3X3_GN_SKIP_C */ 26, /* 17 GN_APPLY_C */ 14, /* 18 CONV3X3_GN_OUT_C */ 13, /* 19 STEM_IM2COL_SPLIT */ 9,
+    /* 20 CONV3X3_GN_SKIP_S */ 29, /* 21 F32_TO_HILO */ 5, /* 22 GN_APPLY_P */ 16, /* 23 CONV3X3_GN_O16 */ 17,
+    /* 24 GN_PARTIAL_C */ 10, /* 25 CONV2D_O16 */ 18};
 
 struct Program {
   std::vector<Op> ops;
@@ -111,9 +124,13 @@ extern "C" int ivid_program_create(void** handle_out) {
 }
 
 // args: nargs slots of 8 bytes each; integers and device pointers as int64, floats as double (see ivid_hip.h)
+extern "C" int ivid_program_op_arity(int op) { return (op >= 1 && op <= IVID_OP_LAST) ? kArity[op] : -1; }
+
 extern "C" int ivid_program_add(void* handle, int op, const void* args, int nargs) {
   Program* p = (Program*)handle;
   if (!p || nargs < 0 || nargs > 32 || (nargs && !args)) return ivid_set_error("program_add: bad arguments", hipSuccess);
+  if (op < 1 || op > IVID_OP_LAST) return ivid_set_error("program_add: unknown op code", hipSuccess);
+  if (nargs != kArity[op]) return ivid_set_error("program_add: argument count does not match the entry point of this op code", hipSuccess);
   if (p->graph) return ivid_set_error("program_add: program already captured", hipSuccess);
   Op o;
   o.code = op;
@@ -217,8 +234,12 @@ struct EngBuf { int kind; unsigned long long nbytes, src, dev; };
 extern "C" int ivid_unet_load(const void* blob, long long nbytes, void** handle_out) {
   if (!blob || nbytes < 64 || !handle_out) return ivid_set_error("unet_load: bad arguments", hipSuccess);
   Reader r{(const unsigned char*)blob, (size_t)nbytes};
-  if (memcmp(r.b, "IVIDENG1", 8) != 0) return ivid_set_error("unet_load: not an ivid engine file (magic)", hipSuccess);
+  if (memcmp(r.b, "IVIDENG", 7) != 0) return ivid_set_error("unet_load: not an ivid engine file (magic)", hipSuccess);
+  if (r.b[7] != '2') return ivid_set_error("unet_load: engine file format version not supported by this library (re-export it)", hipSuccess);
   r.p = 8;
+  // the launch list is a list of calls INTO this library: a file written against other entry-point signatures must not run
+  if (r.get<unsigned>() != (unsigned)IVID_ENGINE_ABI)
+    return ivid_set_error("unet_load: engine file was exported for another IVID_ENGINE_ABI (entry-point signatures changed): re-export it", hipSuccess);
   const unsigned batch = r.get<unsigned>(), has_cls = r.get<unsigned>();
   const unsigned rows = r.get<unsigned>(), cin = r.get<unsigned>(), cout = r.get<unsigned>(), size = r.get<unsigned>();
   const unsigned long long x_bytes = r.get<unsigned long long>(), out_bytes = r.get<unsigned long long>();
@@ -252,6 +273,7 @@ extern "C" int ivid_unet_load(const void* blob, long long nbytes, void** handle_
     Op o;
     o.code = (int)r.get<unsigned>(); o.nargs = (int)r.get<unsigned>();
     if (!r.ok || o.nargs < 0 || o.nargs > 32 || o.code < 1 || o.code > IVID_OP_LAST) { bad = "unet_load: malformed op"; break; }
+    if (o.nargs != kArity[o.code]) { bad = "unet_load: op argument count does not match its entry point"; break; }
     for (int a = 0; a < o.nargs; ++a) {
       const unsigned char tag = r.get<unsigned char>();
       if (tag == 0) o.a[a].i = r.get<long long>();

@@ -25,13 +25,22 @@ HIP launch plan (plan.py) on weights repacked once per precision:
                         island (fp32 storage, bf16 hi + lo operands, 3 MFMAs per product).  Measured on the representative
                         forward set (q-sampled scenes, t in {0..999}): max 8.8e-4 (large) / 8.3e-4 (small), where fp16cx is
                         1.45e-3 and fp16c 1.66e-3 -- the fastest mode INSIDE the 1e-3 tolerance per forward (15 % slower than fp16cx)
+    precision "fp16sa": ADAPTIVE (round 4, the default of `use_fp16` since round 5): fp16s for every forward nobody announced a timestep
+                        for and for announced timesteps t < 250; fp16s WITHOUT its island ("fp16cs") for forwards a sampler announced
+                        with t >= 250 (note_timestep; the samplers of this package do it) -- every row of every representative
+                        forward set is inside the tolerance in the mode its timestep selects (tests/test_adaptive_gpu.py); 8 % faster
+                        than fp16s over a 50-step DDIM schedule
+    precision "fp16sa3": fp16sa + a third tier: plain fp16cx (no split skip convolutions either) from t >= 500.  Inside the tolerance
+                        there on the two UNCONDITIONAL 128^2 backbones (8.4e-4 / 8.8e-4), not with margin on the conditional / SR
+                        ones (9.3e-4 / 9.6e-4): opt-in, and what bench.py's headline rule may pick after checking every row in the run
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
-`use_fp16=True` configs select "fp16s" (the reference's fp16 torso, made to meet the fp32 tolerance on every input); override with the
-extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
+`use_fp16=True` configs select "fp16sa" (the reference's fp16 torso, made to meet the fp32 tolerance on every input; a direct call
+without an announced timestep runs plain fp16s); override with the extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
 without a GPU / without the built library raises.
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -88,7 +97,8 @@ class AdmUnet2d(nn.Module):
             # use_fp16 (adm.py:333,508-514: an fp16 torso) -> fp16 MFMA operands with the compensated trunk and the trunk-critical
             # layers in split precision ("fp16s"): inside the 1e-3 tolerance of the fp32 path on the representative forward set
             # (8.8e-4 max), which a plain fp16 torso -- the reference's own included -- is not (up to 2.1e-3 there)
-            precision = "fp16s" if use_fp16 else "fp32"
+            # since round 5 the adaptive form of that mode: the samplers announce their timestep, forwards at t >= 250 drop the island
+            precision = "fp16sa" if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
         self.max_plans = int(os.environ.get("IVID_MAX_PLANS", "16"))
@@ -99,8 +109,7 @@ class AdmUnet2d(nn.Module):
         self._fan_in = {}
         for name, shape, is_buf in self.spec.schema:
             _attach(self, name, self._init_tensor(name, shape), is_buf)
-        self._packed = None
-        self._plans = {}
+        self._labels_ok = None
 
     # -- init mirrors torch defaults (kaiming-uniform convs/linears, N(0,1) embedding, GN 1/0) and the
     #    reference's zero_module()'d out-convs / proj_out / final conv (adm.py:182,278,486)
@@ -132,40 +141,57 @@ class AdmUnet2d(nn.Module):
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         self.precision = precision
-        # adaptive mode (opt-in, "fp16sa"): `base` for a forward nobody announced a timestep for, `high_t` for one whose caller
-        # announced t >= adaptive_t through note_timestep()
-        self._base_precision, self._high_t_precision = _lib.ADAPTIVE.get(precision, (precision, None))
-        self.adaptive_t = int(os.environ.get("IVID_ADAPTIVE_T", "250"))
+        # adaptive modes (_lib.ADAPTIVE: "fp16sa", "fp16sa3"): a ladder of tiers (mode, t_min); tier 0 serves every forward nobody
+        # announced a timestep for, tier k the forwards announced (note_timestep) with t >= its t_min.  IVID_ADAPTIVE_T /
+        # IVID_ADAPTIVE_T2 move the thresholds of tiers 1 / 2.
+        tiers = list(_lib.ADAPTIVE.get(precision, ((precision, 0),)))
+        for k, env in ((1, "IVID_ADAPTIVE_T"), (2, "IVID_ADAPTIVE_T2")):
+            if k < len(tiers) and env in os.environ:
+                tiers[k] = (tiers[k][0], int(os.environ[env]))
+        assert all(a[1] <= b[1] for a, b in zip(tiers, tiers[1:])), f"adaptive tiers must ascend in t: {tiers}"
+        self._tiers = tiers
+        self._base_precision = tiers[0][0]
+        self._high_t_precision = tiers[1][0] if len(tiers) > 1 else None     # (kept: tier 1 of the two-tier mode)
+        self.adaptive_t = tiers[1][1] if len(tiers) > 1 else int(os.environ.get("IVID_ADAPTIVE_T", "250"))
         self._t_hint = None
-        self._packed = None
-        self._packed_high = None
+        self._packed_tiers = {}
         self._plans = {}
 
     def note_timestep(self, t):
         """The samplers know the (batch-uniform) timestep of the forward they are about to issue as a host integer; the backbone sees
-        it only as a device tensor.  In the adaptive precision mode "fp16sa" the NEXT forward uses it to pick its plan: the
-        split-precision island of fp16s (stem + first encoder level in three MFMA passes, 13 % of a step) buys its tolerance on
-        nearly clean inputs only -- measured on the representative forward set, fp16s without the island ("fp16cs") deviates
-        5.6e-4 at t >= 500 and 6.8e-4 at t = 250 but 1.1e-3 at t <= 20 -- so forwards announced with t >= adaptive_t (default 250,
-        IVID_ADAPTIVE_T) run without it.  A forward nobody announced runs the base mode.  No effect in any other mode."""
-        self._t_hint = int(t)
+        it only as a device tensor.  In an adaptive precision mode the NEXT forward uses it to pick its plan: the split-precision
+        island of fp16s (stem + first encoder level in three MFMA passes, 13 % of a step) buys its tolerance on nearly clean inputs
+        only -- measured on the representative forward sets, fp16s without the island ("fp16cs") deviates 5.6e-4 at t >= 500 and
+        6.8e-4 at t = 250 but 1.1e-3 at t <= 20 -- so forwards announced with t >= adaptive_t (default 250, IVID_ADAPTIVE_T) run
+        without it.  A forward nobody announced runs the base mode (tier 0, the most accurate one).  `None` withdraws an
+        announcement (the samplers do that when their model call returns or raises, so that a hint can never reach a later,
+        unrelated forward).  No effect in any other mode."""
+        self._t_hint = None if t is None else int(t)
+
+    def tier_of(self, t):
+        """Index of the tier a forward announced with timestep t runs in (0 for t = None)."""
+        if t is None:
+            return 0
+        return max(k for k, (_, tmin) in enumerate(self._tiers) if k == 0 or t >= tmin)
+
+    def _take_tier(self):
+        t, self._t_hint = self._t_hint, None
+        return self.tier_of(t)
 
     def _take_high_t(self):
-        t, self._t_hint = self._t_hint, None
-        return self._high_t_precision is not None and t is not None and t >= self.adaptive_t
+        return self._take_tier() >= 1
 
     def convert_to_fp16(self):
         """Reference API (adm.py:508-514): fp16 torso (fp16 MFMA operands, fp32 accumulate / GroupNorm / softmax), with the
-        residual trunk kept as hi + lo fp16 planes and the trunk-critical layers in split precision (precision "fp16s";
-        "fp16c" / "fp16cx" / plain "fp16" remain selectable)."""
-        self.set_precision("fp16s")
+        residual trunk kept as hi + lo fp16 planes and the trunk-critical layers in split precision (precision "fp16sa" = fp16s,
+        minus its island for forwards a sampler announces with t >= 250; "fp16s" / "fp16c" / "fp16cx" / plain "fp16" remain selectable)."""
+        self.set_precision("fp16sa")
 
     def convert_to_fp32(self):
         self.set_precision("fp32")
 
     def _invalidate(self):
-        self._packed = None
-        self._packed_high = None
+        self._packed_tiers = {}
         self._plans = {}
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -200,14 +226,13 @@ class AdmUnet2d(nn.Module):
         return PackedWeights(self.spec, self.state_dict(), dev, _lib.PRECISIONS[precision], comp=_lib.COMPENSATED.get(precision, 0),
                              island=False if precision in _lib.NO_ISLAND else None)
 
-    def _weights(self, high_t=False):
-        if high_t:
-            if self._packed_high is None:
-                self._packed_high = self._pack(self._high_t_precision)
-            return self._packed_high
-        if self._packed is None:
-            self._packed = self._pack(self._base_precision)
-        return self._packed
+    def _weights(self, tier=0):
+        """Repacked weights of one tier (tiers that differ only in layouts the launches do not touch still get their own pack:
+        the island's bf16x3 layouts exist in tier 0 alone, the skip convolutions' lo parts in the fp16s / fp16cs tiers)."""
+        tier = int(tier)
+        if tier not in self._packed_tiers:
+            self._packed_tiers[tier] = self._pack(self._tiers[tier][0])
+        return self._packed_tiers[tier]
 
     def plan(self, batch, stacked=False, high_t=False):
         """Launch plan (activation arena + hipGraph) for one (batch, stacked-CFG) shape.  Plans are kept least recently used first
@@ -215,55 +240,91 @@ class AdmUnet2d(nn.Module):
         sampling job cycles through a handful of shapes -- config 4's batches of 32 + its ragged last batch, config 5's 27-view SR
         batches -- whose arenas are GBs each at bs 64 but fit side by side, while a stream of distinct large batch sizes cannot
         pile arenas up."""
-        key = (batch, stacked, True) if high_t else (batch, stacked)
+        tier = int(high_t)                                          # True = tier 1 (the two-tier mode's high-t plan)
+        if tier >= len(self._tiers):
+            raise ValueError(f"precision mode {self.precision!r} has {len(self._tiers)} tier(s), tier {tier} requested")
+        key = (batch, stacked, tier) if tier else (batch, stacked)
         p = self._plans.pop(key, None)
         if p is None:
-            p = UNetPlan(self.spec, self._weights(high_t), self.device, batch, stacked, self.tile_cfg)
-            need = p.arena.total_bytes()
-            while self._plans and (len(self._plans) >= self.max_plans
-                                   or need + sum(q.arena.total_bytes() for q in self._plans.values()) > self.max_plan_bytes):
-                okey = next(iter(self._plans))
-                old = self._plans.pop(okey)                         # dict order = recency (re-inserted on every hit)
-                torch.cuda.synchronize(self.device)                 # its buffers may still be in flight
-                self._evictions = getattr(self, "_evictions", 0) + 1
-                if self._evictions in (1, 10, 100):                 # a caller cycling through more shapes than fit thrashes: say so
-                    import warnings
-                    warnings.warn(f"AdmUnet2d: launch plan for (batch, stacked) = {okey} evicted ({old.arena.total_bytes() >> 20} MiB "
-                                  f"arena; {self._evictions} evictions so far) to make room for {key}; every miss rebuilds arena + "
-                                  f"hipGraph.  Raise IVID_MAX_PLAN_BYTES (now {self.max_plan_bytes >> 30} GiB) / IVID_MAX_PLANS (now "
-                                  f"{self.max_plans}) if the workload cycles through more shapes.")
-                del old
+            # make room BEFORE building (peak HBM = the cached arenas + the new one otherwise): down to the count limit now, down
+            # to the byte budget once the new arena's size is known; a build that runs out of memory evicts and retries
+            while self._plans and len(self._plans) >= self.max_plans:
+                self._evict(key)
+            weights = self._weights(tier)
+            while True:
+                try:
+                    p = UNetPlan(self.spec, weights, self.device, batch, stacked, self.tile_cfg)
+                    break
+                except torch.OutOfMemoryError:
+                    if not self._plans:
+                        raise
+                    self._evict(key)
+                    torch.cuda.empty_cache()
+            while self._plans and p.arena.total_bytes() + self._cached_bytes() > self.max_plan_bytes:
+                self._evict(key)
         self._plans[key] = p
         return p
+
+    def _cached_bytes(self):
+        """HBM held by the cached plans' arenas and by the repacked weights of every tier in use (the budget counts both)."""
+        return (sum(q.arena.total_bytes() for q in self._plans.values())
+                + sum(w.nbytes() for w in self._packed_tiers.values()))
+
+    def _evict(self, for_key):
+        okey = next(iter(self._plans))
+        old = self._plans.pop(okey)                                 # dict order = recency (re-inserted on every hit)
+        torch.cuda.synchronize(self.device)                         # its buffers may still be in flight
+        self._evictions = getattr(self, "_evictions", 0) + 1
+        if self._evictions in (1, 10, 100):                         # a caller cycling through more shapes than fit thrashes: say so
+            import warnings
+            warnings.warn(f"AdmUnet2d: launch plan for (batch, stacked[, tier]) = {okey} evicted ({old.arena.total_bytes() >> 20} MiB "
+                          f"arena; {self._evictions} evictions so far) to make room for {for_key}; every miss rebuilds arena + "
+                          f"hipGraph.  Raise IVID_MAX_PLAN_BYTES (now {self.max_plan_bytes >> 30} GiB) / IVID_MAX_PLANS (now "
+                          f"{self.max_plans}) if the workload cycles through more shapes.")
+        del old
 
     def export_engine(self, batch, stacked=False, path=None, high_t=False):
         """Freeze the launch plan of one (batch, stacked-CFG) shape -- in the model's current precision mode, with its repacked
         weights -- into an engine file (bytes; written to `path` if given) that `ivid_unet_load` runs WITHOUT Python
         (include/ivid_hip.h; examples/unet_engine_host.c; diffusion/backbones/engine.py for the layout).  `high_t`: the adaptive
         mode's plan for announced timesteps >= adaptive_t (a host that samples from C keeps both engines and picks per step)."""
-        if high_t and self._high_t_precision is None:
-            raise ValueError(f"precision mode {self.precision!r} has no high-t plan (only the adaptive mode 'fp16sa' does)")
+        if int(high_t) >= len(self._tiers):
+            raise ValueError(f"precision mode {self.precision!r} has no high-t plan (only the adaptive modes {sorted(_lib.ADAPTIVE)} do)")
         blob = self.plan(batch, stacked, high_t).export_engine()
         if path is not None:
             with open(path, "wb") as f:
                 f.write(blob)
         return blob
 
+    def _check_labels(self, classes):
+        """nn.Embedding raises IndexError for an out-of-range label (adm.py:549) and the reference asserts on negative labels of a
+        model without null class (adm.py:550-552); the gather kernel would read past the table.  Reading the labels back costs a
+        stream drain, so a `classes` tensor is validated ONCE: a sampler passes the same tensor object to every step of a chain
+        (ddim.py:157-158), and only the first step pays.  The record is a weak reference + the tensor's version counter, so an
+        in-place edit or another tensor (also one that re-uses the address) is checked again."""
+        ok = self._labels_ok
+        if ok is not None and ok[0]() is classes and ok[1] == classes._version:
+            return
+        if classes.numel():
+            lo, hi = int(classes.min()), int(classes.max())
+            assert self.has_null_class or lo >= 0, "this model does not have a null class"
+            if hi >= self.num_classes:
+                raise IndexError(f"class label {hi} out of range for num_classes = {self.num_classes}")
+        self._labels_ok = (weakref.ref(classes), classes._version)
+
     # ---- reference-compatible forward ----
     @torch.no_grad()
     def forward(self, x, times, classes=None):
-        high_t = self._take_high_t()          # an announced timestep is for THIS call only, whatever happens below
+        high_t = self._take_tier()            # an announced timestep is for THIS call only, whatever happens below
         assert classes is None or self.num_classes is not None, "this model is not class-conditioned"
-        if classes is not None:
-            assert classes.shape == (x.shape[0],), "classes must be a 1-D batch of labels"
-            assert self.has_null_class or bool(torch.all(classes >= 0)), "this model does not have a null class"
-            # nn.Embedding raises IndexError for an out-of-range label (adm.py:549); the gather kernel would read past the table
-            if int(classes.max()) >= self.num_classes:
-                raise IndexError(f"class label {int(classes.max())} out of range for num_classes = {self.num_classes}")
         assert x.shape[1:] == (self.in_channels, self.image_size, self.image_size), \
             f"expected input [N,{self.in_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}"
-        if x.shape[0] == 0:   # empty batch: what the reference's torch ops return (no launch)
+        if classes is not None:
+            assert classes.shape == (x.shape[0],), "classes must be a 1-D batch of labels"
+        if x.shape[0] == 0:   # empty batch: what the reference's torch ops return (no launch, no label read-back)
             return x.new_zeros((0, self.out_channels, self.image_size, self.image_size), dtype=torch.float32)
+        if classes is not None:
+            self._check_labels(classes)
         out = self.plan(x.shape[0], False, high_t).run(x.float().contiguous(), times, classes, self.use_graph)
         return out.clone()
 
@@ -273,10 +334,9 @@ class AdmUnet2d(nn.Module):
         `classes`, rows [B,2B) the null class): returns (eps_cond, eps_uncond) views of a static buffer
         that stay valid until the next call.  Replaces the two sequential backbone calls of
         classifier_free_guidance.py:39-42 / inpaint_cfg.py:80-83."""
-        high_t = self._take_high_t()
+        high_t = self._take_tier()
         assert self.num_classes is not None and classes is not None
-        if int(classes.max()) >= self.num_classes:
-            raise IndexError(f"class label {int(classes.max())} out of range for num_classes = {self.num_classes}")
+        self._check_labels(classes)           # one read-back per `classes` tensor, not per step
         b = x.shape[0]
         out = self.plan(b, True, high_t).run(x.float().contiguous(), times, classes, self.use_graph)
         return out[:b], out[b:]

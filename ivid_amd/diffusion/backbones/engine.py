@@ -8,7 +8,8 @@ allocates the buffers, uploads the weights, rebuilds the launch program and hand
 planning happens once, offline; the serving process links libivid_hip.so and nothing else.
 
 Layout (little endian):
-    8 s   magic "IVIDENG1"
+    8 s   magic "IVIDENG2"
+    u32   IVID_ENGINE_ABI of the library the launch list was recorded against (include/ivid_hip.h; any other value is refused)
     u32   batch (rows of x), u32 has_classes, u32 out_rows (batch, or 2 x batch for a stacked-CFG plan), u32 in_channels,
           u32 out_channels, u32 image_size, u64 x_bytes, u64 out_bytes, u32 buffer of x_in / t_in / c_in / out (c_in = 0xffffffff: none)
     u32   n_buffers;  per buffer: u8 kind (0 scratch, 1 constant), u64 nbytes, u64 data offset from the start of the blob (constants)
@@ -23,8 +24,8 @@ import torch
 
 from ... import _lib
 
-MAGIC = b"IVIDENG1"
-HEAD = "<IIIIIIQQIIII"
+MAGIC = b"IVIDENG2"
+HEAD = "<IIIIIIIQQIIII"
 NONE = 0xFFFFFFFF
 
 
@@ -85,7 +86,7 @@ def export_engine(plan):
     has_cls = plan.spec.num_classes is not None
     head = bytearray(MAGIC)
     sp = plan.spec
-    head += struct.pack(HEAD, plan.bsrc, 1 if has_cls else 0, plan.n, sp.in_channels, sp.out_channels, sp.image_size,
+    head += struct.pack(HEAD, _lib.ENGINE_ABI, plan.bsrc, 1 if has_cls else 0, plan.n, sp.in_channels, sp.out_channels, sp.image_size,
                         plan.x_in.numel() * 4, plan.out.numel() * 4,
                         index_of(plan.x_in), index_of(plan.t_in), index_of(plan.c_in) if has_cls else NONE, index_of(plan.out))
     table_len = 4 + len(bufs) * 17
@@ -114,7 +115,7 @@ def parse_engine(blob):
     """The inverse (test / inspection aid): header dict, buffer table, ops with decoded arguments."""
     assert blob[:8] == MAGIC, "not an ivid engine file"
     p = 8
-    batch, has_cls, rows, cin, cout, size, xb, ob, ix, it, ic, io = struct.unpack_from(HEAD, blob, p)
+    abi, batch, has_cls, rows, cin, cout, size, xb, ob, ix, it, ic, io = struct.unpack_from(HEAD, blob, p)
     p += struct.calcsize(HEAD)
     (nb,) = struct.unpack_from("<I", blob, p)
     p += 4
@@ -143,7 +144,7 @@ def parse_engine(blob):
             else:
                 args.append(("null",)); p += 8
         ops.append((code, args))
-    return dict(batch=batch, has_classes=bool(has_cls), out_rows=rows, in_channels=cin, out_channels=cout, image_size=size, x_bytes=xb, out_bytes=ob, x_in=ix, t_in=it, c_in=None if ic == NONE else ic, out=io), bufs, ops
+    return dict(abi=abi, batch=batch, has_classes=bool(has_cls), out_rows=rows, in_channels=cin, out_channels=cout, image_size=size, x_bytes=xb, out_bytes=ob, x_in=ix, t_in=it, c_in=None if ic == NONE else ic, out=io), bufs, ops
 
 
 class Engine:

@@ -167,6 +167,9 @@ class PackedWeights:
     def __getitem__(self, k):
         return self.t[k]
 
+    def nbytes(self):
+        return sum(v.numel() * v.element_size() for v in self.t.values())
+
 
 class _Arena:
     """Stream-ordered buffer pool: a buffer may be handed out again as soon as its last consumer

@@ -63,7 +63,10 @@ class DdimSampler:
         assert c == 4, "the fused step kernel is specialised for RGBD (4-channel) samples"
         t_model = torch.full((b,), ti - 1, dtype=torch.int64, device=x_t.device)
         announce_timestep(self.framework, ti - 1)
-        eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
+        try:
+            eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
+        finally:   # the announcement is for THIS model call: whether it ran, raised, or the framework never called the backbone
+            announce_timestep(self.framework, None)
         rgb = rgb_m = dep = dep_m = convex = None
         w_rgb = w_dep = w_con = -1.0
         # raw pointers with fixed layouts go to the kernel: broadcast like the reference's tensor expressions would

@@ -56,7 +56,10 @@ class DdpmSampler:
         assert x_t.shape[1] == 4, "the fused step kernel is specialised for RGBD (4-channel) samples"
         t_model = torch.full((b,), ti, dtype=torch.int64, device=x_t.device)
         announce_timestep(self.framework, ti)
-        eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
+        try:
+            eps_c, eps_u, strength = framework_eps(self.framework, x_t, t_model, classes, kwargs)
+        finally:   # the announcement is for THIS model call: whether it ran, raised, or the framework never called the backbone
+            announce_timestep(self.framework, None)
         k = self._coef(ti, strength, clip_denoised)
         # drawn every step by the reference, also at t == 0 where it is multiplied by 0 (ddpm.py:128-130)
         noise = noise_fn(tuple(x_t.shape)) if (ti != 0 or kwargs.get("noise_fn")) else None

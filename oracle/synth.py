@@ -12,8 +12,12 @@ import math
 import torch
 
 
-def synth_state_dict(schema, seed=0):
-    """schema: iterable of (name, shape) in state_dict order.  Returns {name: fp32 tensor}."""
+def synth_state_dict(schema, seed=0, variant=None):
+    """schema: iterable of (name, shape) in state_dict order.  Returns {name: fp32 tensor}.
+    variant "trained" (round 5: is a tolerance claim seed luck?): the same draw, then the statistics a TRAINED ADM checkpoint
+    differs by from a fresh one -- GroupNorm gains far from 1 (gamma ~ U(0.2, 3), beta ~ U(-0.5, 0.5)) and FiLM projections four
+    times larger (emb_layers gain 1.2 instead of 0.3: (1 + scale) swings between ~ -1 and 3) -- drawn from a second generator
+    so that variant=None is bit-identical to what every earlier fixture was made from."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     sd = {}
@@ -38,6 +42,19 @@ def synth_state_dict(schema, seed=0):
                 fan_in *= s
             gain = 0.3 if ".emb_layers." in name else 1.0  # keep FiLM scale/shift moderate
             sd[name] = n * (gain / math.sqrt(fan_in))
+    if variant == "trained":
+        g2 = torch.Generator(device="cpu")
+        g2.manual_seed(1000003 + seed)
+        for name, shape in schema:
+            leaf = name.rsplit(".", 1)[-1]
+            is_norm = any(s in name for s in (".in_layers.0.", ".out_layers.0.", ".norm.")) or name.startswith("out.0.")
+            if is_norm:
+                u = torch.rand(tuple(shape), generator=g2, dtype=torch.float32)
+                sd[name] = (0.2 + 2.8 * u) if leaf == "weight" else (u - 0.5)
+            elif ".emb_layers." in name and leaf == "weight":
+                sd[name] = sd[name] * 4.0
+    elif variant is not None:
+        raise ValueError(f"unknown synthetic-checkpoint variant {variant!r}")
     return sd
 
 

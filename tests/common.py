@@ -51,8 +51,11 @@ def schema_for(args):
     return [(n, s) for n, s, _ in build_spec(**args).schema]
 
 
-def synth_weights(args, seed=0):
-    return synth_state_dict(schema_for(args), seed)
+def synth_weights(args, seed=0, variant=None):
+    """seed: an int, or (int, variant) as the FWD_SETS table carries it."""
+    if isinstance(seed, tuple):
+        seed, variant = seed
+    return synth_state_dict(schema_for(args), seed, variant)
 
 
 def seeded_randn(seed, *shape):
@@ -176,6 +179,20 @@ FWD_SETS = {
     "largecond128_mid": (LARGE128_COND, 2, "largecond128_fwd_set_mid", lambda: fwd_set_inputs_cond(128, FWD_SET_T_MID_MORE, 7550, 9050), None),
     "sr256_mid": (SR256, 6, "sr256_fwd_set_mid", lambda: fwd_set_inputs_sr(256, FWD_SET_T_MID_MORE, 7850), SR_CROP),
 }
+# ---- round 5: is the tolerance claim seed luck?  More synthetic checkpoints of the two 128^2 backbones -- further draws of the
+# same recipe, and a "trained-like" variant (oracle/synth.py: GroupNorm gains U(0.2, 3), FiLM projections x 4) -- on rows at the
+# timesteps where the adaptive precision mode changes plans.  (tag -> the same tuple; the seed slot may be (seed, variant))
+FWD_SET_T_SEEDS = (0, 20, 100, 250, 500, 999)
+_seed_rows = lambda: fwd_set_inputs(4, 128, FWD_SET_T_SEEDS, 7300)
+FWD_SETS_SEEDS = {
+    "large128_s11": (LARGE128, 11, "large128_fwd_set_s11", _seed_rows, None),
+    "large128_tr12": (LARGE128, (12, "trained"), "large128_fwd_set_tr12", _seed_rows, None),
+    "small128_s21": (SMALL128, 21, "small128_fwd_set_s21", _seed_rows, None),
+    "small128_s22": (SMALL128, 22, "small128_fwd_set_s22", _seed_rows, None),
+    "small128_s23": (SMALL128, 23, "small128_fwd_set_s23", _seed_rows, None),
+    "small128_tr24": (SMALL128, (24, "trained"), "small128_fwd_set_tr24", _seed_rows, None),
+}
+FWD_SETS.update(FWD_SETS_SEEDS)
 
 
 def fwd_set_deviation(model, tag, device="cuda"):

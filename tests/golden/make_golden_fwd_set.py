@@ -54,6 +54,7 @@ torch.set_num_threads(os.cpu_count())
 
 @torch.no_grad()
 def run(name, args, seed, with_classes, ts=None, seed_base=7000):
+    """seed: int or (int, variant) -- tests/common.synth_weights"""
     ts = C.FWD_SET_T if ts is None else ts
     m = rb.AdmUnet2d(**args).eval()
     sd = C.synth_weights(args, seed)
@@ -82,7 +83,8 @@ def run(name, args, seed, with_classes, ts=None, seed_base=7000):
     man = json.load(open(mf))
     man[name] = dict(note=f"{len(arrays) - len(inputs)} reference forwards (fp32) on x_t = q_sample(synthetic RGBD scene, t), "
                           f"t in {list(ts)}, scenes {[s[0] for s in C.FWD_SET_SCENES]}"
-                          + (", classes [7] / [416] and the null class" if with_classes else ""),
+                          + (", classes [7] / [416] and the null class" if with_classes else "")
+                          + (f"; synthetic checkpoint {seed}" if isinstance(seed, tuple) or seed not in (3, 4) else ""),
                      oracle_vs_reference=dict(rel_l2_max=worst, ref_seconds=round(time.time() - t0, 1)))
     json.dump(man, open(mf, "w"), indent=1, sort_keys=True)
     print(name, man[name], flush=True)
@@ -98,3 +100,7 @@ if "largemid" in which:
     run("large128_fwd_set_mid", C.LARGE128, 4, True, C.FWD_SET_T_MID, 7050)
 if "smallmid" in which:
     run("small128_fwd_set_mid", C.SMALL128, 3, False, C.FWD_SET_T_MID, 7050)
+# round 5: further synthetic checkpoints (more seeds + the "trained-like" variant), rows at the adaptive mode's plan changes
+for tag, (sargs, sseed, sname, _make, _crop) in C.FWD_SETS_SEEDS.items():
+    if tag in which or "seeds" in which:
+        run(sname, sargs, sseed, sargs["num_classes"] is not None, C.FWD_SET_T_SEEDS, 7300)

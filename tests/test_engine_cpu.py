@@ -102,7 +102,13 @@ def test_loader_rejects_malformed_files_before_touching_a_device(cpu_plan):
     bad(blob[:ops_at + 100], "outside the file")                # file ends inside the op list: the constants are checked first
     b = bytearray(blob); struct.pack_into("<I", b, ops_at - 4, len(ops) + 5); bad(b, "")   # more ops than the list holds: runs into the constants' bytes
     b = bytearray(blob); struct.pack_into("<I", b, 8 + hs - 4, len(bufs)); bad(b, "boundary buffer index")
-    b = bytearray(blob); struct.pack_into("<Q", b, 8 + 24, head["x_bytes"] * 2); bad(b, "disagree")
+    b = bytearray(blob); struct.pack_into("<Q", b, 8 + 28, head["x_bytes"] * 2); bad(b, "disagree")
+    # a file written against other entry-point signatures (another IVID_ENGINE_ABI), or in an older container format
+    assert head["abi"] == _lib.ENGINE_ABI
+    b = bytearray(blob); struct.pack_into("<I", b, 8, _lib.ENGINE_ABI + 1); bad(b, "IVID_ENGINE_ABI")
+    b = bytearray(blob); b[7:8] = b"1"; bad(b, "format version")
+    # an op whose argument count is not its entry point's (run_op reads fixed slots): first op of the list
+    b = bytearray(blob); struct.pack_into("<I", b, ops_at + 4, len(ops[0][1]) - 1); bad(b, "argument count")
     b = bytearray(blob); struct.pack_into("<Q", b, 8 + hs + 4 + 1, 16); bad(b, "")   # first buffer shrunk: some pointer / boundary falls outside
     # a constant whose data would lie past the end of the file
     k = next(i for i, x in enumerate(bufs) if x["kind"] == 1)

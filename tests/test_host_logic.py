@@ -182,6 +182,23 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
         assert m._take_high_t() is True
     finally:
         del os.environ["IVID_ADAPTIVE_T"]
+    # three tiers ("fp16sa3"): the LAST tier whose t_min <= t; None withdraws an announcement; IVID_ADAPTIVE_T2 moves tier 2
+    m.set_precision("fp16sa3")
+    assert m._tiers == [("fp16s", 0), ("fp16cs", 250), ("fp16cx", 500)]
+    assert [m.tier_of(t) for t in (None, 0, 249, 250, 499, 500, 999)] == [0, 0, 0, 1, 1, 2, 2]
+    m.note_timestep(700)
+    m.note_timestep(None)
+    assert m._take_tier() == 0
+    m.note_timestep(700)
+    assert m._take_tier() == 2 and m._take_tier() == 0
+    os.environ["IVID_ADAPTIVE_T2"] = "800"
+    try:
+        m.set_precision("fp16sa3")
+        assert m.tier_of(700) == 1 and m.tier_of(800) == 2
+    finally:
+        del os.environ["IVID_ADAPTIVE_T2"]
+    with pytest.raises(ValueError):
+        AdmUnet2d(**C.MINI, precision="fp16sa").plan(1, False, high_t=2)     # refused before anything touches a device
     # the samplers announce through the framework: backbones without note_timestep are left alone
     from ivid_amd.diffusion.samplers.utils import announce_timestep
 
@@ -197,16 +214,19 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
 def test_precision_names_and_reference_fp16_api():
     from ivid_amd import _lib
     from ivid_amd.diffusion.backbones import AdmUnet2d
-    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2}
-    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3}
-    assert _lib.NO_ISLAND == {"fp16cs"} and _lib.ADAPTIVE == {"fp16sa": ("fp16s", "fp16cs")}
+    assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2,
+                               "fp16sa3": 2}
+    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3, "fp16sa3": 3}
+    assert _lib.NO_ISLAND == {"fp16cs"}
+    assert _lib.ADAPTIVE == {"fp16sa": (("fp16s", 0), ("fp16cs", 250)), "fp16sa3": (("fp16s", 0), ("fp16cs", 250), ("fp16cx", 500))}
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16s" and m.dtype == torch.float16          # adm.py:333: the reference's attribute
+    assert m.precision == "fp16sa" and m.dtype == torch.float16         # adm.py:333: the reference's attribute
+    assert m._base_precision == "fp16s"                                 # an unannounced forward runs the full mode
     m.convert_to_fp32(); assert m.precision == "fp32"
-    m.convert_to_fp16(); assert m.precision == "fp16s"
+    m.convert_to_fp16(); assert m.precision == "fp16sa"
     m.set_precision("bf16x3"); assert m.precision == "bf16x3"
     with pytest.raises(ValueError):
         m.set_precision("int8")
@@ -280,10 +300,18 @@ def test_launch_program_object_records_ops_without_a_gpu():
     assert lib.ivid_program_num_ops(h) == 1 and lib.ivid_program_has_graph(h) == 0
     with pytest.raises(_lib.IvidHipError):
         _lib.call("ivid_unet_forward", h, None, None, None, None, 1, None)       # no boundary bound yet
+    # an argument list that is not the entry point's is refused (run_op reads fixed slots), and so is an unknown code
+    for bad_op, bad_n in ((_lib.OP_CODES["ivid_gn_finalize2"], len(args) - 1), (_lib.OP_CODES["ivid_copy"], len(args)), (999, 3)):
+        assert lib.ivid_program_add(h, bad_op, CT.cast(arr, CT.c_void_p), bad_n) != 0
+    assert lib.ivid_program_num_ops(h) == 1
     _lib.call("ivid_program_destroy", h)
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in _lib.OP_CODES.items():
         assert re.search(rf"#define IVID_OP_{name[5:].upper()} {code}\b", hdr), name
+        # the library's arity table (what ivid_program_add / ivid_unet_load check) is the ctypes signature's length
+        assert lib.ivid_program_op_arity(code) == len(_lib.SIGNATURES[name][1]) - 1, name
+    assert lib.ivid_program_op_arity(0) == -1 and lib.ivid_program_op_arity(max(_lib.OP_CODES.values()) + 1) == -1
+    assert re.search(rf"#define IVID_ENGINE_ABI {_lib.ENGINE_ABI}\b", hdr)
 
 
 @pytest.mark.parametrize("cfg", ["MINI", "LARGE128", "SMALL128", "SR256"])
@@ -394,10 +422,19 @@ def test_bench_merges_the_adaptive_modes_two_kernel_tables_by_schedule_share():
     spec.loader.exec_module(bench)
     lo = ({"conv3x3_fused_kernel": dict(ms=70.0, n=35, flop=7e13, byt=1e11), "attn_kernel": dict(ms=2.0, n=16, flop=1e12, byt=1e9)}, {"ivid_gn_apply": 3.0})
     hi = ({"conv3x3_fused_kernel": dict(ms=60.0, n=35, flop=7e13, byt=9e10), "attn_kernel": dict(ms=2.0, n=16, flop=1e12, byt=1e9)}, {"ivid_gn_apply": 3.0, "ivid_copy": 1.0})
-    fam, other = bench.merge_kernel_tables(lo, hi, 0.76)
+    fam, other = bench.merge_kernel_tables([lo, hi], [0.24, 0.76])
     f = fam["conv3x3_fused_kernel"]
     assert abs(f["ms"] - (0.24 * 70 + 0.76 * 60)) < 1e-9 and abs(f["n"] - 35) < 1e-9 and abs(f["flop"] - 7e13) < 1
     assert abs(other["ivid_gn_apply"] - 3.0) < 1e-9 and abs(other["ivid_copy"] - 0.76) < 1e-9
+    fam3, _ = bench.merge_kernel_tables([lo, hi, hi], [0.24, 0.26, 0.5])                       # three tiers
+    assert abs(fam3["conv3x3_fused_kernel"]["ms"] - f["ms"]) < 1e-9
+    # what the bench line says about an adaptive run: tiers, their share of the 50-step schedule, the timed steps each served
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    m = AdmUnet2d(**C.MINI, precision="fp16sa3")
+    pairs = [(20 * (i + 1), 20 * i) for i in reversed(range(50))]
+    rec = bench.adaptive_record(m, pairs, [999, 499, 19, 259])
+    assert [(t["mode"], t["t_min"], t["share_over_the_50_step_schedule"], t["timed_steps"]) for t in rec["tiers"]] == \
+        [("fp16s", 0, 0.24, 1), ("fp16cs", 250, 0.26, 2), ("fp16cx", 500, 0.5, 1)]
     e = bench.roofline_entry("conv3x3_fused_kernel", f, 2500.0, 70.0, 128)
     assert e["launches_per_forward"] == 35.0 and abs(e["avg_launch_ms"] - round(f["ms"] / 35, 4)) < 1e-9
 

@@ -135,14 +135,20 @@ def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
 def test_use_fp16_config_selects_the_fp16_torso_like_the_reference():
     """adm.py:333,508-514: use_fp16 / convert_to_fp16() mean an fp16 torso (not bf16) -- here fp16 MFMA operands with the
     compensated trunk, split-precision skip convolutions and first encoder level (precision "fp16s": inside the 1e-3 tolerance
-    of the fp32 path on the representative forward set, which a plain fp16 torso -- the reference's own included -- is not)."""
+    of the fp32 path on the representative forward set, which a plain fp16 torso -- the reference's own included -- is not), in
+    its adaptive form "fp16sa" since round 5 (a direct call without an announced timestep IS the fp16s forward)."""
     from ivid_amd.diffusion.backbones import AdmUnet2d
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16s" and m.dtype == torch.float16
+    assert m.precision == "fp16sa" and m._base_precision == "fp16s" and m.dtype == torch.float16
     m.convert_to_fp32()
     assert m.precision == "fp32"
     m.convert_to_fp16()
-    assert m.precision == "fp16s"
+    assert m.precision == "fp16sa"
+    m.load_state_dict(C.synth_weights(C.MINI, 1), strict=True)
+    m = m.cuda().eval()
+    ms, _ = build(C.MINI, 1, "fp16s")
+    x, t, cls = C.seeded_randn(2, 2, 4, 32, 32).cuda(), torch.tensor([3, 3]).cuda(), torch.tensor([1, 2]).cuda()
+    assert torch.equal(m(x, t, cls), ms(x, t, cls))
 
 
 def test_small128_forward_matches_reference_golden():

@@ -133,13 +133,19 @@ def main():
     ap.add_argument("--only-extra", action="store_true", help="run the --extra combos only")
     ap.add_argument("--extra-base", default="WAQ", help="rounding classes of the --extra combos' base mode: WAQ = fp16cx, WAHFQ = fp16c")
     ap.add_argument("--mid", action="store_true", help="the rows of the mid-t sets (tests/common.FWD_SET_T_MID) instead of the main set")
+    ap.add_argument("--tag", default="", help="a tests/common.FWD_SETS entry of a 4-channel model (e.g. large128_s11, small128_tr24): its "
+                    "architecture, synthetic checkpoint and rows instead of --model / --mid")
     a = ap.parse_args()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     args, seed = (C.LARGE128, 4) if a.model == "large" else (C.SMALL128, 3)
-    sd = {k: v.float().to(dev) for k, v in C.synth_weights(args, seed).items()}
     ins = C.fwd_set_inputs(args["in_channels"], args["image_size"], *((C.FWD_SET_T_MID, 7050) if a.mid else ()))
+    if a.tag:
+        args, seed, _g, make, _crop = C.FWD_SETS[a.tag]
+        assert args["in_channels"] == 4
+        ins = make()
+    sd = {k: v.float().to(dev) for k, v in C.synth_weights(args, seed).items()}
     has_cls = args.get("num_classes") is not None
     xs, ts, cs, names = [], [], [], []
     for key, x, t, cls in ins:
