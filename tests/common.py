@@ -195,9 +195,10 @@ FWD_SETS_SEEDS = {
 FWD_SETS.update(FWD_SETS_SEEDS)
 
 
-def fwd_set_deviation(model, tag, device="cuda"):
+def fwd_set_deviation(model, tag, device="cuda", with_max_rel=False):
     """rel-L2 of `model` (a loaded AdmUnet2d of FWD_SETS[tag]'s architecture and synthetic checkpoint, in whatever precision mode it
-    is set to) from the live reference's outputs on every row of the set -> {row: deviation}."""
+    is set to) from the live reference's outputs on every row of the set -> {row: deviation}.  with_max_rel: also SURVEY.md 8(c)'s
+    second metric, max-abs error / max-abs reference, per row -> ({row: rel_l2}, {row: max_rel})."""
     args, _seed, gname, make, crop = FWD_SETS[tag]
     g = load_golden(gname)
     ins = make()
@@ -224,8 +225,11 @@ def fwd_set_deviation(model, tag, device="cuda"):
     else:
         ec, eu = None, model(x, t, None).cpu()
     w = (slice(None),) + crop if crop is not None else (slice(None),)
+    mrel = {}
     for i, (key, _, _, _) in enumerate(ins):
         if ec is not None:
             rows[key + "_c"] = rel_l2(ec[i][w], g[key + "_c"])
+            mrel[key + "_c"] = max_rel(ec[i][w], g[key + "_c"])
         rows[key + "_u"] = rel_l2(eu[i][w], g[key + "_u"])
-    return rows
+        mrel[key + "_u"] = max_rel(eu[i][w], g[key + "_u"])
+    return (rows, mrel) if with_max_rel else rows

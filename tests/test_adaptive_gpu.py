@@ -76,7 +76,10 @@ def test_a_sampler_chain_in_the_adaptive_mode_is_the_two_modes_spliced_at_the_th
     assert torch.equal(xa, xc)
 
 
-@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid", "largecond128_mid", "sr256_mid"])
+SEED_TAGS = sorted(C.FWD_SETS_SEEDS)   # round 5: further synthetic checkpoints (more draws + the "trained-like" variant)
+
+
+@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid", "largecond128_mid", "sr256_mid"] + SEED_TAGS)
 def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
     args, seed, gname, make, _crop = C.FWD_SETS[tag]
     g = C.load_golden(gname)

@@ -292,3 +292,37 @@ def test_sample_all_scene_fixture_exercises_the_conditioning_against_the_referen
         assert errs[f"cond{j}_color_frac_within_1_255"] > 0.995 and errs[f"cond{j}_depth_frac_1e-3"] > 0.995, errs
         assert errs[f"cond{j}_depth_convex_frac_1e-3"] > 0.995, errs
     assert errs["view0"] < (1e-4 if precision == "fp32" else 1e-3) and errs["view1"] < 1e-3 and errs["view2"] < 1e-3, errs
+
+
+def test_config4_rank_shard_at_full_size_batch_32_then_the_ragged_batch_of_2():
+    """BASELINE config 4 (10 000 samples, 8 ranks, batches of 32): every rank ends on a ragged batch of 2 next to its 39 batches of
+    32 (parallel.shard_plan; sample.py:56-58,199-202).  The first hardware run must not die on plumbing: at FULL model size (large
+    cfg backbone, the headline precision mode) the two stacked-CFG plans of a rank -- bs 32 and bs 2 -- are built side by side,
+    both run (announced low-t and high-t timesteps: every tier of the adaptive mode), a sample's forward does not depend on the
+    batch it sits in (bitwise), and a plan budget that holds only one of the arenas evicts instead of failing."""
+    from ivid_amd import parallel
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    sp = parallel.shard_plan(10000, 8, 32)
+    assert all(r["samples"] == 1250 and r["batches"] == 40 and r["last_batch"] == 2 for r in sp)
+    m = AdmUnet2d(**C.LARGE128, precision="fp16sa")
+    m.load_state_dict(C.synth_weights(C.LARGE128, 4), strict=True)
+    m = m.cuda().eval()
+    x = C.seeded_randn(11, 32, 4, 128, 128).cuda()
+    cls = (torch.arange(32) * 31 % 1000).cuda()
+    for t in (999, 20):
+        tt = torch.full((32,), t, dtype=torch.long).cuda()
+        m.note_timestep(t)
+        ec, eu = [v.clone() for v in m.forward_cfg(x, tt, cls)]
+        m.note_timestep(t)
+        rc, ru = m.forward_cfg(x[:2], tt[:2], cls[:2])                     # the ragged last batch: its own plan, same bits
+        assert torch.isfinite(ec).all() and torch.equal(rc, ec[:2]) and torch.equal(ru, eu[:2]), t
+    assert len(m._plans) == 4                                               # (32 | 2) x (tier 0 | tier 1), side by side
+    big = max(p.arena.total_bytes() for p in m._plans.values())
+    import warnings
+    m.max_plan_bytes = int(1.2 * big) + sum(w.nbytes() for w in m._packed_tiers.values())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tt = torch.full((3,), 999, dtype=torch.long).cuda()
+        m.note_timestep(999)
+        e3, _ = m.forward_cfg(x[:3], tt, cls[:3])                           # a new shape under the tight budget: evicts, then runs
+    assert torch.equal(e3[:2], ec[:2]) and len(m._plans) < 4

@@ -654,6 +654,9 @@ def test_edge_batches_empty_and_single():
     S = C.MINI["image_size"]
     e = m(torch.zeros(0, 4, S, S, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"), None)
     assert e.shape == (0, 4, S, S) and e.dtype == torch.float32
+    # ... also with an (empty) label tensor: no label read-back on an empty batch (torch.empty(0).max() raises)
+    e = m(torch.zeros(0, 4, S, S, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"), torch.zeros(0, dtype=torch.long, device="cuda"))
+    assert e.shape == (0, 4, S, S)
     x = C.seeded_randn(77, 1, 4, S, S)
     t = torch.full((1,), 321, dtype=torch.long)
     cls = torch.tensor([5])
@@ -693,6 +696,14 @@ def test_out_of_range_class_label_raises_like_nn_embedding():
     with pytest.raises(IndexError):
         m.forward_cfg(x, t, torch.tensor([416, 1]).cuda())
     assert torch.isfinite(m(x, t, torch.tensor([9, -1]).cuda())).all()
+    # a label tensor is read back ONCE (a sampler passes the same object to every step): the second call with it does not
+    # synchronise; an in-place edit or another tensor is checked again
+    good = torch.tensor([3, 4]).cuda()
+    m(x, t, good)
+    assert m._labels_ok[0]() is good
+    good[1] = 10
+    with pytest.raises(IndexError):
+        m(x, t, good)
 
 
 def test_plan_cache_keeps_plans_under_a_byte_budget():

@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--only-extra", action="store_true", help="run the --extra combos only")
     ap.add_argument("--extra-base", default="WAQ", help="rounding classes of the --extra combos' base mode: WAQ = fp16cx, WAHFQ = fp16c")
     ap.add_argument("--mid", action="store_true", help="the rows of the mid-t sets (tests/common.FWD_SET_T_MID) instead of the main set")
+    ap.add_argument("--combos", default="", help="semicolon list: run these named combos only (fp16c, fp16cx, cx+skip = fp16cs, "
+                    "cx+skip+X(ib1,2) = fp16s, ...)")
     ap.add_argument("--tag", default="", help="a tests/common.FWD_SETS entry of a 4-channel model (e.g. large128_s11, small128_tr24): its "
                     "architecture, synthetic checkpoint and rows instead of --model / --mid")
     a = ap.parse_args()
@@ -174,12 +176,14 @@ def main():
     def selx(xfix, base="WAQ"):   # both operands exact (three MFMA passes) in the blocks of xfix
         return lambda k, s: k in base and not skip(s) and not any(s.startswith(p) for p in xfix)
     ob = lambda *i: tuple(f"output_blocks.{j}.0." for j in i)
-    combos = {"cx+skip+X(ib1)": selx(ib(1)), "cx+skip+X(ib1,2)": selx(ib(1, 2)), "cx+skip+X(ib1,2,3)": selx(ib(1, 2, 3)),
+    combos.update({"cx+skip+X(ib1)": selx(ib(1)), "cx+skip+X(ib1,2)": selx(ib(1, 2)), "cx+skip+X(ib1,2,3)": selx(ib(1, 2, 3)),
               "cx+skip+X(ib1,2,ob12,13,14)": selx(ib(1, 2) + ob(12, 13, 14)),
               "cx+skip+X(ib1,2,3,ob11,12,13,14)": selx(ib(1, 2, 3) + ob(11, 12, 13, 14)),
               "c+skip+X(ib1,2,3)": selx(ib(1, 2, 3), "WAHQF"),
               "cx+X(ib1,2,3)": lambda k, s: k in "WAQ" and not any(s.startswith(p) for p in ib(1, 2, 3)),
-              "cx+skip+X(ib1,2,3)+W(ob12,13,14)": (lambda k, s: selx(ib(1, 2, 3))(k, s) and not (k == "W" and any(s.startswith(p) for p in ob(12, 13, 14))))}
+              "cx+skip+X(ib1,2,3)+W(ob12,13,14)": (lambda k, s: selx(ib(1, 2, 3))(k, s) and not (k == "W" and any(s.startswith(p) for p in ob(12, 13, 14))))})
+    if a.combos:
+        combos = {k: combos[k] for k in a.combos.split(";")}
     if a.only_extra:
         combos = {}
     for spec in filter(None, a.extra.split(";")):
