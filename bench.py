@@ -49,16 +49,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"; bf16x3 is priced against the bf16 peak with ALGORITHMIC
 # flops (its 3 MFMAs per product are overhead, not work)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp16c": 2500.0, "fp16cx": 2500.0, "fp16s": 2500.0, "fp16cs": 2500.0, "fp16sa": 2500.0,
-               "fp16sa3": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
+               "fp16sa3": 2500.0, "fp16sx": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE_FWD = {"large": 613.78, "small": 156.56, "sr256": 697.84}  # BASELINE.md §2 (2 x MACs of conv/linear + attention)
-DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2, "fp16sa3": 2}
+DTYPE_CODE = {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2, "fp16sa3": 2, "fp16sx": 2}
 ESZ = {0: 4, 1: 2, 2: 2, 3: 4}
 
 
 # `dtype` of the bench line = the arithmetic type of the MFMA operands; `precision_mode` = the mode of this package
 ARITH = {"fp32": "fp32", "bf16": "bf16", "fp16": "fp16", "fp16c": "fp16", "fp16cx": "fp16", "fp16s": "fp16", "fp16cs": "fp16",
-         "fp16sa": "fp16", "fp16sa3": "fp16", "bf16x3": "bf16"}
+         "fp16sa": "fp16", "fp16sa3": "fp16", "fp16sx": "fp16", "bf16x3": "bf16"}
 MODE_NOTE = {
     "fp32": "fp32 storage, exact fp32 MFMA",
     "bf16": "bf16 storage and MFMA operands, fp32 accumulate",
@@ -69,10 +69,12 @@ MODE_NOTE = {
              "split-precision island (fp32 storage, bf16 hi + lo operands, 3 MFMA passes)",
     "fp16cs": "fp16s without its split-precision island (stem and first encoder level in plain fp16cx form): inside the tolerance "
               "only on inputs that carry diffusion noise (t >= 250 on the representative forward set)",
-    "fp16sa": "adaptive (what use_fp16 configs select): fp16s for forwards at t < 250 (IVID_ADAPTIVE_T), fp16cs (no island) for forwards "
-              "the sampler announces with t >= 250 -- every row of the forward sets is checked in the mode its timestep selects",
-    "fp16sa3": "adaptive, three tiers: fp16s at t < 250, fp16cs (no island) at 250 <= t < 500, plain fp16cx (no split skip convolutions "
+    "fp16sa": "adaptive (what use_fp16 configs select): fp16s for forwards at t < 150 (IVID_ADAPTIVE_T), fp16cs (no island) for forwards "
+              "the sampler announces with t >= 150 -- every row of the forward sets is checked in the mode its timestep selects",
+    "fp16sa3": "adaptive, three tiers: fp16s at t < 150, fp16cs (no island) at 150 <= t < 500, plain fp16cx (no split skip convolutions "
                "either) from t >= 500 (IVID_ADAPTIVE_T2) -- every row of the forward sets is checked in the mode its timestep selects",
+    "fp16sx": "adaptive, the STRICT ladder: bf16x3 at t < 250, fp16s at 250 <= t < 500, fp16cs from t >= 500 -- holds BOTH parity metrics "
+              "of SURVEY.md 8(c) (rel-L2 and max-abs / |ref|_inf) under 1e-3 on every row of the forward sets",
     "bf16x3": "fp32 storage; operands split into bf16 hi + lo, 3 bf16 MFMAs per product",
 }
 PARITY_TOL = 1e-3                                           # BASELINE.json north_star: outputs within 1e-3 of the reference
@@ -127,11 +129,17 @@ def parity_checks(model_name, precisions, dev, C):
                 r["fwd_noise_t999"] = max(C.rel_l2(ec.cpu(), g["eps"]), C.rel_l2(eu.cpu(), g["eps_uncond"]))
             else:
                 r["fwd_noise_t%d" % int(g["t"])] = C.rel_l2(gm(xg, tg, None).cpu(), g["eps"])
-        rows = C.fwd_set_deviation(gm, tag, dev)
+        rows, mrel = C.fwd_set_deviation(gm, tag, dev, with_max_rel=True)
         if tag + "_mid" in C.FWD_SETS:        # the same checkpoint between the low-noise rows (where the adaptive modes change plans)
-            rows.update({"mid/" + k: v for k, v in C.fwd_set_deviation(gm, tag + "_mid", dev).items()})
+            r2, m2 = C.fwd_set_deviation(gm, tag + "_mid", dev, with_max_rel=True)
+            rows.update({"mid/" + k: v for k, v in r2.items()})
+            mrel.update({"mid/" + k: v for k, v in m2.items()})
         worst = max(rows, key=rows.get)
         r.update(fwd_set_max=rows[worst], fwd_set_argmax=worst, fwd_set_min=min(rows.values()), fwd_set_n=len(rows))
+        # SURVEY.md 8(c)'s second metric, max-abs error / max-abs reference, on the same rows (reported; the rule of the headline is
+        # the rel-L2 form of north_star's "within 1e-3 relative" -- `both_metrics` says whether the max-norm form holds as well)
+        wm = max(mrel, key=mrel.get)
+        r.update(fwd_set_max_rel=mrel[wm], fwd_set_max_rel_argmax=wm)
         if fw is not None:
             kw = dict(classes=ccls, strength=strength) if ccls is not None else {}
             ch = samplers.DdimSampler(fw).sample(2, noise=x_T, steps=steps, verbose=False, **kw)
@@ -155,13 +163,14 @@ def parity_checks(model_name, precisions, dev, C):
         gm.load_state_dict(C.synth_weights(gargs, C.FWD_SETS[st][1]), strict=True)
         for prec in precisions:
             gm.set_precision(prec)
-            rows = C.fwd_set_deviation(gm, st, dev)
+            rows, mrel = C.fwd_set_deviation(gm, st, dev, with_max_rel=True)
             worst = max(rows, key=rows.get)
             o = out[prec].setdefault("other_checkpoints", {})
-            o[st] = {"max": round(rows[worst], 8), "argmax": worst}
+            o[st] = {"max": round(rows[worst], 8), "argmax": worst, "max_rel": round(max(mrel.values()), 8)}
     for prec in precisions:
         if "other_checkpoints" in out[prec]:
             out[prec]["other_checkpoints_max"] = max(v["max"] for v in out[prec]["other_checkpoints"].values())
+            out[prec]["other_checkpoints_max_rel"] = max(v["max_rel"] for v in out[prec]["other_checkpoints"].values())
         out[prec] = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in out[prec].items()}
     del gm
     torch.cuda.empty_cache()
@@ -188,6 +197,11 @@ def within_tolerance(r):
     return bool(r) and all(r[k] <= PARITY_TOL for k in keys)
 
 
+def both_metrics(r):
+    """within_tolerance AND SURVEY.md 8(c)'s max-norm metric (max-abs error / max-abs reference) <= PARITY_TOL on every forward-set row."""
+    return within_tolerance(r) and all(r[k] <= PARITY_TOL for k in ("fwd_set_max_rel", "other_checkpoints_max_rel") if k in r)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +213,7 @@ def parse_args(argv=None):
                     help="auto: the fastest mode within 1e-3 of the reference on every in-run check (forward set, chain, teacher-forced eps)")
     ap.add_argument("--parity-precision", default="bf16x3", choices=sorted(DTYPE_CODE),
                     help="second, parity-grade mode timed beside the headline ('none' via --no-parity-mode)")
-    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c,fp16cx,fp16sa3,fp16sa,fp16s",
+    ap.add_argument("--extra-precisions", default="bf16,fp16,fp16c,fp16cx,fp16sa3,fp16sa,fp16s,fp16sx",
                     help="comma list of further modes timed briefly beside the headline (fp16 = the reference's use_fp16 torso)")
     ap.add_argument("--guidance", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -550,6 +564,11 @@ def main():
                              "live reference's fp32 outputs are all <= %g, every figure measured in this run" % PARITY_TOL,
                      "speed_order": list(SPEED_ORDER), "tolerance": PARITY_TOL, "checks": parity_what,
                      "within_tolerance": {m: within_tolerance(dev_tab.get(m, {})) for m in SPEED_ORDER},
+                     "both_metrics_within_tolerance": {m: both_metrics(dev_tab.get(m, {})) for m in dev_tab},
+                     "metric_note": "north_star's 'within 1e-3 relative' is applied as rel-L2 = |a - b| / |b| (what `value` is picked by); "
+                                    "SURVEY.md 8(c) also names max-abs / |b|_inf, which on these outputs is by construction ~1.5-1.7 x the "
+                                    "rel-L2 figure (maximum of a Gaussian error field over 65 k values against a smooth reference's peak): "
+                                    "`parity.fwd_set_max_rel` reports it, `strict_both_metrics` is the fastest mode that holds both",
                      "picked": a.precision, "verified": bool(dev_tab)}
         if not dev_tab:
             selection["note"] = ("no committed reference output exists for this model: NO mode was verified here; the parity-grade "
@@ -722,7 +741,7 @@ def main():
     for pp in extra:
         model.set_precision(pp)
         psteps = max(2, min(a.steps, 5))
-        if pp in ("fp16sa", "fp16sa3"):     # the cost of an adaptive mode depends on t: stride 7 over the schedule needs ~10 steps to be fair
+        if pp in ("fp16sa", "fp16sa3", "fp16sx"):     # the cost of an adaptive mode depends on t: stride 7 over the schedule needs ~10 steps to be fair
             psteps = max(psteps, min(a.steps, 10))
         pdt = timed(psteps, 2)
         pf = fwd_per_step * psteps * world / pdt
@@ -740,6 +759,7 @@ def main():
         if "chain_samples" in dev_tab[a.precision]:
             result["chain_rel_l2_vs_reference"] = dev_tab[a.precision]["chain_samples"]
         result["parity_checks"] = parity_what
+        result["parity"]["both_metrics_within_tolerance"] = both_metrics(dev_tab[a.precision])
         for pp in extra:
             modes[pp]["parity"] = dict(dev_tab[pp], within_tolerance=within_tolerance(dev_tab[pp]))
             modes[pp]["within_tolerance"] = within_tolerance(dev_tab[pp])
@@ -750,6 +770,17 @@ def main():
                                      frac_note="algorithmic FLOPs / dense bf16 MFMA peak (the 3 MFMAs per product are overhead)")
     elif a.precision == a.parity_precision or within_tolerance(dev_tab.get(a.precision, {})):
         result["parity_mode"] = {"dtype": ARITH[a.precision], "precision_mode": a.precision, "note": "the headline mode itself is inside the tolerance"}
+    timed_vals = {m: v["value"] for m, v in modes.items()}
+    timed_vals[a.precision] = result["value"]
+    if result.get("parity_mode", {}).get("value") is not None:
+        timed_vals[result["parity_mode"]["precision_mode"]] = result["parity_mode"]["value"]
+    strict = [m for m in timed_vals if m in dev_tab and both_metrics(dev_tab[m])]
+    if strict:   # the fastest mode (by this run's own timings) that holds rel-L2 AND the max-norm metric on every check
+        vals = {m: timed_vals[m] for m in strict}
+        best = max(vals, key=vals.get)
+        result["strict_both_metrics"] = {"precision_mode": best, "value": vals[best], "unit": result["unit"],
+                                         "fwd_set_max": dev_tab[best]["fwd_set_max"], "fwd_set_max_rel": dev_tab[best]["fwd_set_max_rel"],
+                                         "candidates": vals}
     if modes:
         result["other_modes"] = list(modes.values())
 

@@ -26,13 +26,16 @@ HIP launch plan (plan.py) on weights repacked once per precision:
                         forward set (q-sampled scenes, t in {0..999}): max 8.8e-4 (large) / 8.3e-4 (small), where fp16cx is
                         1.45e-3 and fp16c 1.66e-3 -- the fastest mode INSIDE the 1e-3 tolerance per forward (15 % slower than fp16cx)
     precision "fp16sa": ADAPTIVE (round 4, the default of `use_fp16` since round 5): fp16s for every forward nobody announced a timestep
-                        for and for announced timesteps t < 250; fp16s WITHOUT its island ("fp16cs") for forwards a sampler announced
-                        with t >= 250 (note_timestep; the samplers of this package do it) -- every row of every representative
+                        for and for announced timesteps t < 150; fp16s WITHOUT its island ("fp16cs") for forwards a sampler announced
+                        with t >= 150 (note_timestep; the samplers of this package do it) -- every row of every representative
                         forward set is inside the tolerance in the mode its timestep selects (tests/test_adaptive_gpu.py); 8 % faster
                         than fp16s over a 50-step DDIM schedule
     precision "fp16sa3": fp16sa + a third tier: plain fp16cx (no split skip convolutions either) from t >= 500.  Inside the tolerance
                         there on the two UNCONDITIONAL 128^2 backbones (8.4e-4 / 8.8e-4), not with margin on the conditional / SR
                         ones (9.3e-4 / 9.6e-4): opt-in, and what bench.py's headline rule may pick after checking every row in the run
+    precision "fp16sx": the STRICT ladder (round 5): bf16x3 below t = 250, fp16s up to 500, fp16cs above -- keeps BOTH parity metrics of
+                        SURVEY.md 8(c) (rel-L2 and max-abs / |ref|_inf; the second is ~1.6 x the first on these outputs) under 1e-3
+                        on every row of every forward set; an unannounced forward runs bf16x3
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
 `use_fp16=True` configs select "fp16sa" (the reference's fp16 torso, made to meet the fp32 tolerance on every input; a direct call
 without an announced timestep runs plain fp16s); override with the extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
@@ -97,7 +100,7 @@ class AdmUnet2d(nn.Module):
             # use_fp16 (adm.py:333,508-514: an fp16 torso) -> fp16 MFMA operands with the compensated trunk and the trunk-critical
             # layers in split precision ("fp16s"): inside the 1e-3 tolerance of the fp32 path on the representative forward set
             # (8.8e-4 max), which a plain fp16 torso -- the reference's own included -- is not (up to 2.1e-3 there)
-            # since round 5 the adaptive form of that mode: the samplers announce their timestep, forwards at t >= 250 drop the island
+            # since round 5 the adaptive form of that mode: the samplers announce their timestep, forwards at t >= 150 drop the island
             precision = "fp16sa" if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
@@ -152,7 +155,7 @@ class AdmUnet2d(nn.Module):
         self._tiers = tiers
         self._base_precision = tiers[0][0]
         self._high_t_precision = tiers[1][0] if len(tiers) > 1 else None     # (kept: tier 1 of the two-tier mode)
-        self.adaptive_t = tiers[1][1] if len(tiers) > 1 else int(os.environ.get("IVID_ADAPTIVE_T", "250"))
+        self.adaptive_t = tiers[1][1] if len(tiers) > 1 else int(os.environ.get("IVID_ADAPTIVE_T", str(_lib.ISLAND_T)))
         self._t_hint = None
         self._packed_tiers = {}
         self._plans = {}
@@ -161,9 +164,9 @@ class AdmUnet2d(nn.Module):
         """The samplers know the (batch-uniform) timestep of the forward they are about to issue as a host integer; the backbone sees
         it only as a device tensor.  In an adaptive precision mode the NEXT forward uses it to pick its plan: the split-precision
         island of fp16s (stem + first encoder level in three MFMA passes, 13 % of a step) buys its tolerance on nearly clean inputs
-        only -- measured on the representative forward sets, fp16s without the island ("fp16cs") deviates 5.6e-4 at t >= 500 and
-        6.8e-4 at t = 250 but 1.1e-3 at t <= 20 -- so forwards announced with t >= adaptive_t (default 250, IVID_ADAPTIVE_T) run
-        without it.  A forward nobody announced runs the base mode (tier 0, the most accurate one).  `None` withdraws an
+        only -- measured on the representative forward sets, fp16s without the island ("fp16cs") deviates 5.6e-4 at t >= 500,
+        6.8e-4 at t = 250, 8.1e-4 at t = 150 but 1.1e-3 at t <= 20 -- so forwards announced with t >= adaptive_t (default 150,
+        IVID_ADAPTIVE_T; 250 until round 5) run without it.  A forward nobody announced runs the base mode (tier 0, the most accurate one).  `None` withdraws an
         announcement (the samplers do that when their model call returns or raises, so that a hint can never reach a later,
         unrelated forward).  No effect in any other mode."""
         self._t_hint = None if t is None else int(t)
@@ -184,7 +187,7 @@ class AdmUnet2d(nn.Module):
     def convert_to_fp16(self):
         """Reference API (adm.py:508-514): fp16 torso (fp16 MFMA operands, fp32 accumulate / GroupNorm / softmax), with the
         residual trunk kept as hi + lo fp16 planes and the trunk-critical layers in split precision (precision "fp16sa" = fp16s,
-        minus its island for forwards a sampler announces with t >= 250; "fp16s" / "fp16c" / "fp16cx" / plain "fp16" remain selectable)."""
+        minus its island for forwards a sampler announces with t >= 150; "fp16s" / "fp16c" / "fp16cx" / plain "fp16" remain selectable)."""
         self.set_precision("fp16sa")
 
     def convert_to_fp32(self):

@@ -27,14 +27,39 @@ def as_f32(t):
     return t.float().contiguous()
 
 
+_CANON = None
+
+
+def equivalent_timestep(framework, t_model):
+    """The adaptive precision modes' tier thresholds are timesteps of the schedule every reference config uses (1000 steps, linear
+    betas: configs/*.json `framework.args`).  A framework with another schedule announces the canonical timestep of the SAME noise
+    level instead of its own index: the largest canonical t whose signal share abar_t is not below this step's (so the tier picked
+    is at least as accurate as the one the canonical schedule would pick for an input this clean).  Identity for the canonical
+    schedule; frameworks without a `betas` table are passed through."""
+    global _CANON
+    betas = getattr(framework, "betas", None)
+    if betas is None or t_model is None:
+        return t_model
+    if _CANON is None:
+        cb = np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)
+        _CANON = (cb, np.cumprod(1.0 - cb))
+    b = np.asarray(betas, dtype=np.float64)
+    if b.shape == _CANON[0].shape and np.allclose(b, _CANON[0], rtol=1e-12, atol=0.0):
+        return int(t_model)
+    abar = float(np.cumprod(1.0 - b)[int(t_model)])
+    n_cleaner_or_equal = int(np.searchsorted(-_CANON[1], -abar, side="right"))      # canonical steps with abar_t >= abar
+    return max(0, n_cleaner_or_equal - 1)
+
+
 def announce_timestep(framework, t_model):
     """Tell the backbone the host-side value of the timestep tensor the next `model_inference` call will carry (the samplers build
     that tensor from a Python int; the backbone would have to synchronise to read it back): AdmUnet2d.note_timestep, which only the
-    adaptive precision mode looks at.  Other backbones are left alone."""
+    adaptive precision modes look at -- as the equivalent timestep of the canonical 1000-step linear schedule (equivalent_timestep).
+    None withdraws the announcement.  Other backbones are left alone."""
     bb = getattr(framework, "backbone", None)
     bb = getattr(bb, "module", bb)
     if hasattr(bb, "note_timestep"):
-        bb.note_timestep(t_model)
+        bb.note_timestep(equivalent_timestep(framework, t_model))
 
 
 def framework_eps(framework, x_t, t_model, classes, kwargs):

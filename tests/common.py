@@ -193,6 +193,10 @@ FWD_SETS_SEEDS = {
     "small128_tr24": (SMALL128, (24, "trained"), "small128_fwd_set_tr24", _seed_rows, None),
 }
 FWD_SETS.update(FWD_SETS_SEEDS)
+# round 5: the conditional / SR models between t = 100 and 250 (the island threshold of the adaptive modes moved to 150)
+FWD_SET_T_MID2 = (150, 200)
+FWD_SETS["largecond128_mid2"] = (LARGE128_COND, 2, "largecond128_fwd_set_mid2", lambda: fwd_set_inputs_cond(128, FWD_SET_T_MID2, 7580, 9080), None)
+FWD_SETS["sr256_mid2"] = (SR256, 6, "sr256_fwd_set_mid2", lambda: fwd_set_inputs_sr(256, FWD_SET_T_MID2, 7880), SR_CROP)
 
 
 def fwd_set_deviation(model, tag, device="cuda", with_max_rel=False):

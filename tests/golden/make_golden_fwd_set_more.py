@@ -112,4 +112,10 @@ if "condmid" in which:
     run("largecond128_fwd_set_mid", C.LARGE128_COND, 2, C.FWD_SETS["largecond128_mid"][3](), check_cond, None)
 if "srmid" in which:
     run("sr256_fwd_set_mid", C.SR256, 6, C.FWD_SETS["sr256_mid"][3](), check_sr, C.SR_CROP)
+# round 5: t = 150, 200 (the island threshold of the adaptive modes moved from 250 to 150)
+TS, FILL_BASE = C.FWD_SET_T_MID2, 9080
+if "condmid2" in which:
+    run("largecond128_fwd_set_mid2", C.LARGE128_COND, 2, C.FWD_SETS["largecond128_mid2"][3](), check_cond, None)
+if "srmid2" in which:
+    run("sr256_fwd_set_mid2", C.SR256, 6, C.FWD_SETS["sr256_mid2"][3](), check_sr, C.SR_CROP)
 json.dump(man, open(man_path, "w"), indent=1, sort_keys=True)

@@ -1,8 +1,9 @@
-"""The adaptive precision mode "fp16sa" (opt-in; ivid_amd/diffusion/backbones/adm.py note_timestep): fp16s, except that a forward
-whose caller announced a timestep >= adaptive_t (default 250) runs fp16s WITHOUT its split-precision island ("fp16cs").  The
-island buys its tolerance on nearly clean inputs only; every row of every forward set -- the four BASELINE backbones plus the
-mid-t sets of the large and small models (t = 50, 100, 150, 350) -- is checked here in the mode its timestep selects, against the
-live reference's outputs (the conditional and SR models have mid-t sets too: t = 100, 250, 350)."""
+"""The adaptive precision modes (ivid_amd/diffusion/backbones/adm.py note_timestep; "fp16sa" is what use_fp16 configs select): fp16s,
+except that a forward whose caller announced a timestep >= adaptive_t (150 since round 5) runs fp16s WITHOUT its split-precision
+island ("fp16cs"); "fp16sa3" also drops the split skip convolutions from t >= 500 (plain fp16cx); "fp16sx" is the strict ladder that
+holds both parity metrics.  The island buys its tolerance on nearly clean inputs only; every row of every forward set -- the four
+BASELINE backbones, their mid-t sets (t = 50 .. 350), and six further synthetic checkpoints of the two 128^2 backbones (more draws +
+a "trained-like" variant) -- is checked here in the mode its timestep selects, against the live reference's outputs."""
 import pytest
 import torch
 
@@ -58,7 +59,7 @@ def test_a_sampler_chain_in_the_adaptive_mode_is_the_two_modes_spliced_at_the_th
     T = ms_["fp16sa"].adaptive_t
     cls = torch.tensor([2, 9]).cuda()
     x_a = x_b = C.seeded_randn(3, 2, 4, 32, 32).cuda() * 0.05           # small: the synthetic-weight chain must stay finite
-    pairs = [(t, t - 100) for t in range(1000, 0, -100)]
+    pairs = [(t, t - 100) for t in range(1000, 0, -100)]       # t - 1 = 999 .. 99: the last step runs below the threshold
     used = set()
     for t, tp in pairs:
         x_a = sm["fp16sa"].sample_once(x_a, t, tp, cls, strength=0.5).pred_x_prev
@@ -79,7 +80,8 @@ def test_a_sampler_chain_in_the_adaptive_mode_is_the_two_modes_spliced_at_the_th
 SEED_TAGS = sorted(C.FWD_SETS_SEEDS)   # round 5: further synthetic checkpoints (more draws + the "trained-like" variant)
 
 
-@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid", "largecond128_mid", "sr256_mid"] + SEED_TAGS)
+@pytest.mark.parametrize("tag", ["large128", "small128", "largecond128", "sr256", "large128_mid", "small128_mid", "largecond128_mid", "sr256_mid",
+                                 "largecond128_mid2", "sr256_mid2"] + SEED_TAGS)
 def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
     args, seed, gname, make, _crop = C.FWD_SETS[tag]
     g = C.load_golden(gname)
@@ -101,3 +103,16 @@ def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
         assert v == out["fp16cs" if tof(key) >= T else "fp16s"][key], key
     assert max(out["fp16sa"].values()) < BAR, (tag, out["fp16sa"])
     assert max(out["fp16s"].values()) < BAR, (tag, out["fp16s"])           # the headline mode on the mid-t rows as well
+    # the STRICT ladder "fp16sx" (bf16x3 / fp16s / fp16cs at t < 250 / < 500 / >= 500): BOTH metrics of SURVEY.md 8(c) -- rel-L2 and
+    # max-abs error / max-abs reference -- under 1e-3 on every row
+    m.set_precision("fp16sx")
+    rows, mrel = C.fwd_set_deviation(m, tag, with_max_rel=True)
+    G.report(f"fwd_set/{tag}/fp16sx", max=max(rows.values()), max_rel_max=max(mrel.values()), max_rel_argmax=max(mrel, key=mrel.get))
+    assert max(rows.values()) < BAR and max(mrel.values()) < 1e-3, (tag, max(rows.values()), max(mrel, key=mrel.get), max(mrel.values()))
+    # the three-tier ladder "fp16sa3" (+ plain fp16cx from t >= 500) on the UNCONDITIONAL 128^2 backbones, where it is inside the bar
+    if tag.startswith(("large128", "small128")):
+        m.set_precision("fp16sa3")
+        rows3 = C.fwd_set_deviation(m, tag)
+        G.report(f"fwd_set/{tag}/fp16sa3", max=max(rows3.values()), argmax=max(rows3, key=rows3.get))
+        assert max(rows3.values()) < BAR, (tag, max(rows3, key=rows3.get), max(rows3.values()))
+        assert all(v == out["fp16sa"][k] for k, v in rows3.items() if tof(k) < 500)

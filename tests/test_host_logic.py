@@ -165,9 +165,9 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
     consumed by ONE query, and IVID_ADAPTIVE_T moves the threshold."""
     from ivid_amd.diffusion.backbones import AdmUnet2d
     m = AdmUnet2d(**C.MINI, precision="fp16sa")
-    assert (m._base_precision, m._high_t_precision, m.adaptive_t) == ("fp16s", "fp16cs", 250)
+    assert (m._base_precision, m._high_t_precision, m.adaptive_t) == ("fp16s", "fp16cs", 150)
     assert m._take_high_t() is False
-    for t, want in ((249, False), (250, True), (999, True), (0, False)):
+    for t, want in ((149, False), (150, True), (999, True), (0, False)):
         m.note_timestep(t)
         assert m._take_high_t() is want and m._take_high_t() is False
     m.set_precision("fp16s")
@@ -184,8 +184,8 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
         del os.environ["IVID_ADAPTIVE_T"]
     # three tiers ("fp16sa3"): the LAST tier whose t_min <= t; None withdraws an announcement; IVID_ADAPTIVE_T2 moves tier 2
     m.set_precision("fp16sa3")
-    assert m._tiers == [("fp16s", 0), ("fp16cs", 250), ("fp16cx", 500)]
-    assert [m.tier_of(t) for t in (None, 0, 249, 250, 499, 500, 999)] == [0, 0, 0, 1, 1, 2, 2]
+    assert m._tiers == [("fp16s", 0), ("fp16cs", 150), ("fp16cx", 500)]
+    assert [m.tier_of(t) for t in (None, 0, 149, 150, 499, 500, 999)] == [0, 0, 0, 1, 1, 2, 2]
     m.note_timestep(700)
     m.note_timestep(None)
     assert m._take_tier() == 0
@@ -209,16 +209,38 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
     assert m._take_high_t() is True
     announce_timestep(type("X", (), {"backbone": object()}), 5)
     announce_timestep(object(), 5)
+    # a framework with ANOTHER schedule announces the canonical (1000-step linear) timestep of the same noise level, rounded toward
+    # the cleaner side; the canonical schedule announces itself unchanged
+    import numpy as np
+    from ivid_amd.diffusion.frameworks.utils import get_betas_by_name
+    from ivid_amd.diffusion.samplers.utils import equivalent_timestep
+    canon = type("F", (), {"betas": get_betas_by_name("linear", 1000)})
+    assert [equivalent_timestep(canon, t) for t in (0, 249, 250, 999)] == [0, 249, 250, 999]
+    ab1000 = np.cumprod(1 - canon.betas)
+    for name, n in (("linear", 250), ("linear", 4000), ("cosine", 1000)):
+        f = type("F", (), {"betas": get_betas_by_name(name, n)})
+        ab = np.cumprod(1 - f.betas)
+        prev = -1
+        for t in range(0, n, max(1, n // 50)):
+            te = equivalent_timestep(f, t)
+            assert 0 <= te <= 999 and te >= prev and (ab1000[te] >= ab[t] or te == 0), (name, n, t, te)     # never noisier than the real input
+            assert te == 999 or ab1000[te + 1] < ab[t]                                                       # ... and the largest such
+            prev = te
+    f250 = type("F", (), {"betas": get_betas_by_name("linear", 250), "backbone": m})
+    announce_timestep(f250, 124)                       # the middle of a 250-step schedule is canonical t ~ 500, not 124
+    assert 480 <= m._t_hint <= 520
+    m.note_timestep(None)
 
 
 def test_precision_names_and_reference_fp16_api():
     from ivid_amd import _lib
     from ivid_amd.diffusion.backbones import AdmUnet2d
     assert _lib.PRECISIONS == {"fp32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "fp16c": 2, "fp16cx": 2, "fp16s": 2, "fp16cs": 2, "fp16sa": 2,
-                               "fp16sa3": 2}
-    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3, "fp16sa3": 3}
+                               "fp16sa3": 2, "fp16sx": 2}
+    assert _lib.COMPENSATED == {"fp16c": 1, "fp16cx": 2, "fp16s": 3, "fp16cs": 3, "fp16sa": 3, "fp16sa3": 3, "fp16sx": 3}
     assert _lib.NO_ISLAND == {"fp16cs"}
-    assert _lib.ADAPTIVE == {"fp16sa": (("fp16s", 0), ("fp16cs", 250)), "fp16sa3": (("fp16s", 0), ("fp16cs", 250), ("fp16cx", 500))}
+    assert _lib.ADAPTIVE == {"fp16sa": (("fp16s", 0), ("fp16cs", 150)), "fp16sa3": (("fp16s", 0), ("fp16cs", 150), ("fp16cx", 500)),
+                             "fp16sx": (("bf16x3", 0), ("fp16s", 250), ("fp16cs", 500))}
     hdr = open(os.path.join(C.ROOT, "include", "ivid_hip.h")).read()
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
@@ -434,7 +456,7 @@ def test_bench_merges_the_adaptive_modes_two_kernel_tables_by_schedule_share():
     pairs = [(20 * (i + 1), 20 * i) for i in reversed(range(50))]
     rec = bench.adaptive_record(m, pairs, [999, 499, 19, 259])
     assert [(t["mode"], t["t_min"], t["share_over_the_50_step_schedule"], t["timed_steps"]) for t in rec["tiers"]] == \
-        [("fp16s", 0, 0.24, 1), ("fp16cs", 250, 0.26, 2), ("fp16cx", 500, 0.5, 1)]
+        [("fp16s", 0, 0.14, 1), ("fp16cs", 150, 0.36, 2), ("fp16cx", 500, 0.5, 1)]
     e = bench.roofline_entry("conv3x3_fused_kernel", f, 2500.0, 70.0, 128)
     assert e["launches_per_forward"] == 35.0 and abs(e["avg_launch_ms"] - round(f["ms"] / 35, 4)) < 1e-9
 

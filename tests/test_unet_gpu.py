@@ -312,13 +312,18 @@ def _forward_set(tag):
         assert abs(float(x.double().sum()) - float(g[key + "_xsum"])) < 1e-3 * max(1.0, abs(float(g[key + "_xsum"]))), key
     m, _ = build(args, seed, "fp32")
     out = {}
+    mr = {}
     for prec in ("fp32", "bf16x3", "fp16s", "fp16cx", "fp16c", "fp16", "bf16"):
         m.set_precision(prec)
-        rows = C.fwd_set_deviation(m, tag)
+        rows, mrel = C.fwd_set_deviation(m, tag, with_max_rel=True)
         worst = max(rows, key=rows.get)
         out[prec] = rows[worst]
-        G.report(f"fwd_set/{tag}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), **rows)
-    print(f"forward set {tag}: max rel-L2 vs the reference per mode:", {k: "%.3e" % v for k, v in out.items()})
+        mr[prec] = max(mrel.values())
+        G.report(f"fwd_set/{tag}/{prec}", max=rows[worst], argmax=worst, min=min(rows.values()), max_rel_max=mr[prec],
+                 max_rel_argmax=max(mrel, key=mrel.get), **rows)
+    print(f"forward set {tag}: max rel-L2 vs the reference per mode:", {k: "%.3e" % v for k, v in out.items()},
+          "| max-abs / |ref|_inf:", {k: "%.3e" % v for k, v in mr.items()})
+    out["max_rel"] = mr
     return out
 
 
@@ -333,6 +338,12 @@ def test_forward_set_max_deviation_per_mode(tag):
     e = _forward_set(tag)
     for prec, bar in SET_BAR.items():
         assert e[prec] < bar, (tag, prec, e[prec])
+    # SURVEY.md 8(c)'s second metric, max-abs error / max-abs reference, on EVERY row: the exact modes hold it with the same margin;
+    # a 16-bit forward's error field is Gaussian (kurtosis 3.6) while a smooth input's reference output peaks at only ~3.3 sigma, so
+    # the max-norm figure is by construction ~1.5-1.7 x the rel-L2 one: fp16s stays under 1.6e-3 (1.4e-3 measured on clean smooth
+    # inputs at t <= 20, under 1e-3 from t = 250 on) -- the ladder that keeps BOTH metrics under 1e-3 is "fp16sx" (tests/test_adaptive_gpu.py)
+    for prec, bar in (("fp32", 1e-4), ("bf16x3", 1e-4), ("fp16s", 1.6e-3)):
+        assert e["max_rel"][prec] < bar, (tag, prec, e["max_rel"][prec])
     assert e["fp16s"] < e["fp16cx"] < e["fp16c"] < e["fp16"] < 3e-3, e
     assert e["bf16"] < 3e-2
 
@@ -358,6 +369,43 @@ def test_config2_teacher_forced_eps_on_the_chains_own_inputs():
     print("config 2, teacher-forced guided eps:", {p: {k: "%.2e" % v for k, v in e.items()} for p, e in errs.items()})
     for prec, bar in (("fp32", 1e-4), ("bf16x3", 1e-4), ("fp16s", PARITY_BAR)):
         assert max(errs[prec].values()) < bar, (prec, errs[prec])
+
+
+@pytest.mark.parametrize("chain", ["smallcfg_ddpm250_cfg3", "mini128cond_inpaint50"])
+def test_teacher_forced_guided_eps_at_strength_3_on_the_chains_own_inputs(chain):
+    """Per-step parity at the guidance strength configs 3 / 4 / 5 use (inference/sample.py:79,117): the guided eps
+    (1 + 3) eps_c - 3 eps_u (classifier_free_guidance.py:39-42, inpaint_cfg.py:80-83) on the tensors the REFERENCE chain fed its
+    backbone (tests/golden/make_golden_steps_s3.py: DDPM-250 + CFG 3.0 at t = 249 .. 0 of its 250-step schedule; InpaintCFG 3.0 +
+    DDIM-50 on the scene conditioning at t = 999, 599, 99 -- the 10-channel input with that step's hole noise).  Strength 3 puts
+    1 + 2s = 7 on a forward's deviation: the exact modes (fp32, bf16x3) hold 1e-3 per step with two orders of margin, the 16-bit
+    modes hold it for the SAMPLES of these chains (tests below) but NOT for every single guided eps -- measured here, reported in
+    profiles/, stated in bench.py's c3 / c4 / c5 lines ("sample-level parity"); bf16x3 is the per-step-exact mode."""
+    g = C.load_golden(chain + "_steps")
+    args, seed = (C.SMALL128_CFG, 5) if chain.startswith("smallcfg") else (C.MINI128_COND, 2)
+    fw_T = 250 if chain.startswith("smallcfg") else 1000
+    from ivid_amd.diffusion.frameworks.utils import get_betas_by_name
+    from ivid_amd.diffusion.samplers.utils import equivalent_timestep
+    fwk = type("F", (), {"betas": get_betas_by_name("linear", fw_T)})
+    m, _ = build(args, seed, "fp32")
+    cls = torch.from_numpy(g["classes"]).cuda()
+    steps = sorted(int(k[len("eps_step"):]) for k in g if k.startswith("eps_step"))
+    errs = {}
+    for prec in ("fp32", "bf16x3", "fp16sx", "fp16s", "fp16sa", "fp16cx", "fp16"):
+        m.set_precision(prec)
+        errs[prec] = {}
+        for k in steps:
+            x = torch.from_numpy(g[f"in_step{k}"]).cuda()
+            t = torch.full((x.shape[0],), int(g[f"t_step{k}"]), dtype=torch.long).cuda()
+            m.note_timestep(equivalent_timestep(fwk, int(g[f"t_step{k}"])))        # what the samplers announce
+            ec, eu = m.forward_cfg(x, t, cls)
+            errs[prec][f"t{int(g[f't_step{k}'])}"] = C.rel_l2((4.0 * ec - 3.0 * eu).cpu(), g[f"eps_step{k}"])
+        G.report(f"teacher_forced_s3/{chain}_{prec}", **errs[prec])
+    print(chain, "teacher-forced guided eps, strength 3.0:", {p: {k: "%.2e" % v for k, v in e.items()} for p, e in errs.items()})
+    for prec in ("fp32", "bf16x3"):
+        assert max(errs[prec].values()) < 1e-4, (prec, errs[prec])
+    for prec in ("fp16s", "fp16sa", "fp16sx"):      # bounded, not inside 1e-3 on every step: 7 x a forward's 3-9e-4
+        assert max(errs[prec].values()) < 4e-3, (prec, errs[prec])
+    assert max(errs["fp16s"].values()) <= max(errs["fp16"].values())
 
 
 def test_fp16s_plan_runs_the_first_level_as_a_split_island_and_every_skip_conv_in_split_precision():
