@@ -319,10 +319,11 @@ def test_config4_rank_shard_at_full_size_batch_32_then_the_ragged_batch_of_2():
     assert len(m._plans) == 4                                               # (32 | 2) x (tier 0 | tier 1), side by side
     big = max(p.arena.total_bytes() for p in m._plans.values())
     import warnings
-    m.max_plan_bytes = int(1.2 * big) + sum(w.nbytes() for w in m._packed_tiers.values())
+    m.max_plan_bytes = int(0.5 * big) + sum(w.nbytes() for w in m._packed_tiers.values())     # neither bs-32 arena fits any more
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         tt = torch.full((3,), 999, dtype=torch.long).cuda()
         m.note_timestep(999)
         e3, _ = m.forward_cfg(x[:3], tt, cls[:3])                           # a new shape under the tight budget: evicts, then runs
-    assert torch.equal(e3[:2], ec[:2]) and len(m._plans) < 4               # (ec: the t = 999 pass of the loop above)
+    assert torch.equal(e3[:2], ec[:2])                                      # (ec: the t = 999 pass of the loop above)
+    assert (3, True, 1) in m._plans and not any(k[0] == 32 for k in m._plans), sorted(m._plans)
