@@ -161,7 +161,8 @@ def main():
     ref = forward(sd, args, x, t, cl, q0)
     sites = list(q0.seen)
     res = dict(rows=names, macs=q0.macs, sites={}, combos={})
-    combos = {"fp16c": lambda k, s: k in "WAHQF", "fp16cx": lambda k, s: k in "WAQ", "W": lambda k, s: k == "W",
+    combos = {"fp16c": lambda k, s: k in "WAHQF", "fp16cx": lambda k, s: k in "WAQ", "cx+H": lambda k, s: k in "WAQH",
+              "cx+F": lambda k, s: k in "WAQF", "W": lambda k, s: k == "W",
               "A": lambda k, s: k == "A", "H": lambda k, s: k == "H", "F": lambda k, s: k == "F", "Q": lambda k, s: k == "Q"}
     # candidate selective modes: fp16cx + every 1x1 skip_connection in split precision (+ a second MFMA pass with the weights'
     # lo part on the 3x3 convolutions of the first ResBlocks)
