@@ -116,3 +116,25 @@ def test_every_forward_set_row_in_the_mode_its_timestep_selects(tag):
         G.report(f"fwd_set/{tag}/fp16sa3", max=max(rows3.values()), argmax=max(rows3, key=rows3.get))
         assert max(rows3.values()) < BAR, (tag, max(rows3, key=rows3.get), max(rows3.values()))
         assert all(v == out["fp16sa"][k] for k, v in rows3.items() if tof(k) < 500)
+
+
+def test_a_full_size_ladder_chain_is_reproducible_bit_for_bit():
+    """The headline workload in miniature: BASELINE config 2's sampler (DDIM, CFG 0.5) on the large cfg backbone in the three-tier
+    ladder, 25 steps from t = 1000 (so every tier's plan is built, captured into its own hipGraph and switched to mid-chain), bs 4.
+    Two runs from the same x_T must agree bit for bit -- tier switches between graphs on one stream leave no race or stale buffer --
+    and the chain must equal the one a fresh model produces."""
+    from ivid_amd.diffusion import frameworks, samplers
+    outs = []
+    for fresh in range(2):
+        m = build(C.LARGE128, 4, "fp16sa3")
+        fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+        smp = samplers.DdimSampler(fw)
+        x_T = C.seeded_randn(5, 4, 4, 128, 128).cuda()
+        cls = torch.tensor([1, 22, 333, 999]).cuda()
+        for rep in range(2 if fresh == 0 else 1):
+            outs.append(smp.sample(4, noise=x_T, classes=cls, steps=25, strength=0.5, verbose=False).samples.clone())
+        assert sorted(k[2] if len(k) > 2 else 0 for k in m._plans) == [0, 1, 2]      # all three tiers ran
+        del m, fw, smp
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
