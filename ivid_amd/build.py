@@ -78,9 +78,16 @@ def _build_host_example(verbose):
            "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"host example failed to build:\n{r.stdout}\n{r.stderr}")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        err = None if r.returncode == 0 else f"{r.stdout}\n{r.stderr}"
+    except OSError as e:                      # no gcc on this machine
+        err = str(e)
+    if err is not None:
+        # an optional example must not turn a library that linked into a failed build: say so and carry on (the test that runs
+        # the C host, tests/test_engine_gpu.py, reports the missing binary itself)
+        import warnings
+        warnings.warn(f"examples/unet_engine_host.c was not built (the library itself is fine):\n{err}")
 
 
 if __name__ == "__main__":
