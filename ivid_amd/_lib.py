@@ -35,7 +35,7 @@ NO_ISLAND = {"fp16cs"}
 # every row of every forward set: bf16x3 below t = 250, fp16s up to 500, fp16cs above.
 # Thresholds (timesteps of the canonical 1000-step linear schedule), read off the per-timestep deviation table of the mode ladder on
 # ten synthetic checkpoints of four backbones (profiles/r05_mode_ladder_per_t.json): without the island (fp16cs) the worst row is
-# 8.1e-4 at t = 150 and 9.3e-4 at t = 50; without the split skips too (fp16cx) 8.8e-4 at t = 500 on the unconditional backbones.
+# 8.6e-4 at t = 150 (SR-256; 8.1e-4 on the 128^2 backbones) and 1.04e-3 at t = 50; without the split skips too (fp16cx) 8.8e-4 at t = 500 on the unconditional backbones.
 ISLAND_T, SKIPS_T = 150, 500
 ADAPTIVE = {"fp16sa": (("fp16s", 0), ("fp16cs", ISLAND_T)),
             "fp16sa3": (("fp16s", 0), ("fp16cs", ISLAND_T), ("fp16cx", SKIPS_T)),
