@@ -367,14 +367,16 @@ class UNetPlan:
         self._conv(_lib.F32, x.data_ptr(), k, None, 0, wname, out.data_ptr(), res.data_ptr() if res is not None else None,
                    1 if res is not None else 0, 0, self.n, 1, 1, cout, 1)
 
-    def _gn_coeffs(self, x0: _Act, x1, gname, film_off):
-        """GroupNorm statistics of cat(x0,x1) folded with gamma/beta (+FiLM) -> per-(image, channel) (a, b) buffer."""
+    def _gn_coeffs(self, x0: _Act, x1, gname, film_off, film_row0=0):
+        """GroupNorm statistics of cat(x0,x1) folded with gamma/beta (+FiLM) -> per-(image, channel) (a, b) buffer.
+        film_row0: image i of x0 takes the FiLM row film_row0 + i (a tensor shared by both halves of a stacked CFG batch is
+        normalised once per half, each with its own class embedding)."""
         n, side = x0.n, x0.side
         c0, c1 = x0.c, (x1.c if x1 is not None else 0)
         c = c0 + c1
         hw = side * side
         ab = self.arena.get(n * c * 2 * 4)
-        film = self.embproj.data_ptr() if film_off is not None else None
+        film = self.embproj.data_ptr() + film_row0 * self.spec.emb_total * 4 if film_off is not None else None
         fo = film_off if film_off is not None else 0
         gw, gb = self.w[gname + ".weight"].data_ptr(), self.w[gname + ".bias"].data_ptr()
         if x0.stats is not None and (x1 is None or x1.stats is not None):
@@ -478,7 +480,12 @@ class UNetPlan:
         up4 = (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0 and op.cout > 32)
         # fp16cx: h1 (between the block's two convolutions) carries a lo plane too: out_layers' GroupNorm then
         # sees the unrounded in_layers result (not behind the phase-form up-convolution, whose epilogue scatters single planes)
-        h1 = self._new(n, so, op.cout, stats=True, trunk=self.comp_in and not up4)
+        # First ResBlock of a stacked CFG forward (rows >= bsrc repeat x and t with the null class, classifier_free_guidance.py:39-42):
+        # the stem output and this block's in_layers (GroupNorm without FiLM, SiLU, conv) do not depend on the class, so rows
+        # bsrc.. would recompute rows 0..bsrc-1 bit for bit: h1 exists for ONE half only
+        share = (fused and self.share_cfg and not self._first_res_done and self.n == 2 * self.bsrc and skip is None and not self.debug
+                 and not op.has_skip_conv)
+        h1 = self._new(self.bsrc if share else n, so, op.cout, stats=True, trunk=self.comp_in and not up4)
         xpool = None
         if (op.mode == "up" and skip is None and x.side <= self.up4_max_side and (x.side * x.side) % 64 == 0
                 and op.cout > 32):
@@ -490,27 +497,14 @@ class UNetPlan:
                       h1.ptr, n, x.side, x.side, op.cout, self.tile_cfg or self._tile_up4,
                       h1.stats.data_ptr() if h1.stats is not None else None)
             self._free(act1)
-        elif fused and self.share_cfg and not self._first_res_done and self.n == 2 * self.bsrc and skip is None and not self.debug:
-            # First ResBlock of a stacked CFG forward (rows >= bsrc repeat x and t with the null class,
-            # classifier_free_guidance.py:39-42): the stem output and this block's in_layers (GroupNorm without FiLM, SiLU,
-            # conv) do not depend on the class, so rows bsrc.. would recompute rows 0..bsrc-1 bit for bit.  The convolution
-            # runs on the first half; its output and its GroupNorm partials are duplicated (image-major layouts: a half is
-            # one contiguous block).
-            half = self.bsrc
-            xh = _Act(x.buf, half, x.side, x.c, x.stats, lo=x.lo)
+        elif share:
+            # the convolution runs on the first half of x; out_layers below reads its result for BOTH halves (round 5: two
+            # half-batch launches with the same h1 pointer instead of duplicating h1 and its statistics with ivid_copy)
+            xh = _Act(x.buf, self.bsrc, x.side, x.c, x.stats, lo=x.lo)
             xh.stats_blk = x.stats_blk
-            h1h = _Act(h1.buf, half, so, op.cout, h1.stats, lo=h1.lo)
             ab1 = self._gn_coeffs(xh, None, op.prefix + ".in_layers.0", None)
-            self._conv3_gn(xh, None, ab1, False, op.prefix + ".in_layers.2", h1h, None, 0)
-            h1.stats_blk = h1h.stats_blk
+            self._conv3_gn(xh, None, ab1, False, op.prefix + ".in_layers.2", h1, None, 0)
             self.arena.put(ab1)
-            nb = half * so * so * op.cout * self.esz
-            self._rec("ivid_copy", h1.ptr + nb, h1.ptr, nb)
-            if h1.lo is not None:
-                self._rec("ivid_copy", h1.lo_ptr + nb, h1.lo_ptr, nb)
-            if h1.stats is not None:
-                sb = half * (so * so // h1.stats_blk) * op.cout * 2 * 4
-                self._rec("ivid_copy", h1.stats.data_ptr() + sb, h1.stats.data_ptr(), sb)
         elif fused:
             ab1 = self._gn_coeffs(x, skip, op.prefix + ".in_layers.0", None)
             self._conv3_gn(x, skip, ab1, op.mode == "up", op.prefix + ".in_layers.2", h1, None, 0)
@@ -524,6 +518,8 @@ class UNetPlan:
             self._conv(self.dtype, act1.ptr, op.cin, None, 0, op.prefix + ".in_layers.2", h1.ptr, None, 0, 0, n, so, so,
                        op.cout, 9, out_act=h1, out_lo=h1.lo_ptr)
             self._free(act1)
+        if share:
+            return self._res_out_shared(op, x, h1, so)
         if fused2:
             ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off)
         else:
@@ -589,6 +585,45 @@ class UNetPlan:
             self._free(act2)
         if r is not None:
             self._free(r)
+        return out
+
+    def _res_out_shared(self, op: Res, x: _Act, h1: _Act, so):
+        """out_layers of the first ResBlock of a stacked CFG forward (same-size block without skip convolution, fused kernels):
+        h1 holds the class-independent in_layers result of ONE half; each half of the batch is its own launch -- GroupNorm + FiLM
+        coefficients from that half's class embedding rows, residual and output at that half's offset -- reading the same h1.
+        Bit-identical to one full-batch launch on a duplicated h1 (a tile's arithmetic does not know its image index)."""
+        assert op.mode == "same" and not op.has_skip_conv and h1.n == self.bsrc and x.c == op.cout and x.side == so
+        half, n = self.bsrc, self.n
+        self._first_res_done = True
+        out = self._new(n, so, op.cout, stats=True, trunk=True)
+        out.stats_blk = 128
+        island = self.dtype == _lib.BF16X3 and self._main_mode[0] != _lib.BF16X3 and self.island_o16
+        keep32 = True
+        if island:
+            out.twin = self._new16(n, so, op.cout)
+            keep32 = op.prefix != self._island_last
+        px = so * so * op.cout                                   # elements per image
+
+        def view(a, hf, esz):
+            """half hf of activation a as its own _Act (buffer views: the arena only ever sees the parents)"""
+            off = hf * half * px * esz
+            v = _Act(a.buf[off:], half, a.side, a.c, None, lo=a.lo)
+            v.stats_blk = a.stats_blk
+            if a.stats is not None:
+                v.stats = a.stats[hf * half * (so * so // a.stats_blk) * a.c * 2 * 4:]
+            return v
+        for hf in (0, 1):
+            ab2 = self._gn_coeffs(h1, None, op.prefix + ".out_layers.0", op.emb_off, film_row0=hf * half)
+            xv, ov = view(x, hf, self.esz), view(out, hf, self.esz)
+            if island:
+                tv = view(out.twin, hf, 2)
+                self._rec("ivid_conv3x3_gn_o16", h1.ptr, h1.c, None, 0, ab2.data_ptr(), self.w[op.prefix + ".out_layers.3.weight"].data_ptr(),
+                          self.w[op.prefix + ".out_layers.3.bias"].data_ptr(), ov.ptr if keep32 else None, tv.ptr, tv.lo_ptr,
+                          xv.ptr, 1, half, so, so, op.cout, ov.stats.data_ptr() if ov.stats is not None else None)
+            else:
+                self._conv3_gn(h1, None, ab2, False, op.prefix + ".out_layers.3", ov, xv.ptr, 1, res_lo=xv.lo_ptr)
+            self.arena.put(ab2)
+        self._free(h1)
         return out
 
     def _attn(self, op: Attn, x: _Act):

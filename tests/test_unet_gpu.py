@@ -99,22 +99,23 @@ def test_mini_stacked_cfg_forward_matches_two_reference_calls():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_stacked_cfg_forward_shares_the_class_independent_prefix_bit_exactly(precision, monkeypatch):
-    """Stacked CFG forward: the first ResBlock's in_layers convolution is computed for one half of the batch and duplicated
-    (nothing in front of the first FiLM depends on the class, adm.py:214-218).  The result must be BIT-identical to the plan
-    that computes both halves (IVID_NO_CFG_SHARE=1), and the shared plan must really hold the copies."""
+    """Stacked CFG forward: the first ResBlock's in_layers convolution is computed for ONE half of the batch (nothing in front of
+    the first FiLM depends on the class, adm.py:214-218); out_layers reads that result for both halves -- one half-batch launch
+    each, with the half's own class embedding (round 5; rounds 2-4 duplicated the tensor with ivid_copy).  The result must be
+    BIT-identical to the plan that computes both halves (IVID_NO_CFG_SHARE=1), and the shared plan must really be the shared one."""
     g, x, t, cls = fwd_inputs("mini_fwd", C.MINI, 0, 3)
     cls = torch.tensor([3, 7, 1])
-    outs, ncopy = [], []
+    outs, nfused, ncopy = [], [], []
     for env in ("0", "1"):
         monkeypatch.setenv("IVID_NO_CFG_SHARE", env)
         m, _ = build(C.MINI, 0, precision)
         ec, eu = m.forward_cfg(x.cuda(), t.cuda(), cls.cuda())
         outs.append((ec.clone(), eu.clone()))
-        plan = next(iter(m._plans.values())) if hasattr(m, "_plans") else None
-        ncopy.append(sum(1 for _, name, _ in plan.launches if name == "ivid_copy") if plan is not None else -1)
+        plan = next(iter(m._plans.values()))
+        nfused.append(sum(1 for _, name, _ in plan.launches if name.startswith("ivid_conv3x3_gn") and "out" not in name))
+        ncopy.append(sum(1 for _, name, _ in plan.launches if name == "ivid_copy"))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    if ncopy[0] >= 0:
-        assert ncopy[0] == 2 and ncopy[1] == 0, ncopy
+    assert nfused[0] == nfused[1] + 1 and ncopy == [0, 0], (nfused, ncopy)     # in_layers on a half + out_layers per half vs 1 + 1
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16", "fp16c", "fp16cx", "fp16s", "bf16x3"])
