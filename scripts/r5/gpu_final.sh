@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 closing validation on the GPU box: the full parity suite, smoke(), the default bench line (what the driver runs), the same
-# workload over the WHOLE 50-step schedule, config 4 end to end, and a shortened config-5 run (code path of the SR deviation record).
+# workload over the WHOLE 50-step schedule, then the PMC passes and rocprofv3 kernel statistics of the headline ladder.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -25,11 +25,11 @@ timeout 600 python bench.py --precision fp16sa3 --steps 50 --warmup 2 --no-cpu-b
 python -c "
 import json
 d=json.loads(open('gpurun_out/bench_fp16sa3_50steps.json').read().strip().splitlines()[-1]); print('50 steps (the whole schedule):', d['value'], d['ms_per_step'], d['adaptive']['tiers'])"
-timeout 900 python bench.py --config c4 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err
-echo "c4 exit $?"; python -c "
-import json
-d=json.loads(open('gpurun_out/bench_c4.json').read().strip().splitlines()[-1]); print('c4', d['value'], d['seconds_per_batch'], d['precision_mode'])"
-timeout 900 python bench.py --config c5 --c3-steps-uncond 20 --c3-steps-cond 4 > gpurun_out/bench_c5_short.json 2> gpurun_out/bench_c5_short.err
-echo "c5 (shortened) exit $?"; python -c "
-import json
-d=json.loads(open('gpurun_out/bench_c5_short.json').read().strip().splitlines()[-1]); print('c5 short', d['value'], d.get('sr_forward_set_deviation'))" || tail -5 gpurun_out/bench_c5_short.err
+# (config 4 and config 5 end to end were run by separate calls of `python bench.py --config c4|c5`: profiles/r05_bench_c4_fp16sa.json,
+#  r05_bench_c5_fp16sa_sr_bf16.json)
+# PMC passes + kernel statistics of the headline ladder at the closing sources (profiles/r05_pmc_*_fp16sa3.json, r05_kernel_stats_fp16sa3.csv)
+IVID_COMMIT=${IVID_COMMIT:-unknown} PREC=fp16sa3 bash scripts/r5/gpu_pmc.sh > gpurun_out/pmc_r5.log 2>&1; tail -3 gpurun_out/pmc_r5.log
+rm -rf gpurun_out/stats_fp16sa3
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/stats_fp16sa3 -o p -- python bench.py --precision fp16sa3 --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-breakdown --no-parity-mode > gpurun_out/bench_profiled_fp16sa3.json 2> gpurun_out/stats_fp16sa3.log
+f=$(find gpurun_out/stats_fp16sa3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/kernel_stats_fp16sa3.csv && head -4 gpurun_out/kernel_stats_fp16sa3.csv | cut -c1-160
+find gpurun_out/stats_fp16sa3 -name "*.csv" -size +3M -delete
