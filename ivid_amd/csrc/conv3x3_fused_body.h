@@ -2,6 +2,9 @@
 // shapes (FusedShape<WIDE>), included by conv3x3_fused.hip (WIDE: Cout > 128, the C entry points) and conv3x3_fused128.hip
 // (NARROW: Cout <= 128).  Read the header comment of conv3x3_fused.hip first.
 #pragma once
+#ifndef IVID_EXP
+#define IVID_EXP 0   // development builds only (scripts/r6/build_exp.py): bit mask of experimental / timing-only code paths
+#endif
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -216,7 +219,11 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     } else {
       u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f));
       ob &= keep;
+#if IVID_EXP & 8   // timing only: no LDS store of the transformed piece
+      asm volatile("" :: "v"(ob));
+#else
       if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * PPP * AROW) = ob;
+#endif
     }
   };
   // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction)
@@ -241,6 +248,56 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
       const f32x2 y = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
       f[e] = y[0];
       f[e + 1] = y[1];
+    }
+    store_piece(j, f, sAdst);
+  };
+  // The main loop runs the same transform in two halves (round 6): xform_lin reads the chunk's coefficients of this thread's
+  // channel piece in ONE batch and leaves v = x*a + b -- the 16 coefficient registers are dead after VE/2 instructions and the
+  // step's fragment reads are issued into them; the one-piece form above re-used a single register quadruple and paid four LDS
+  // round trips in a row in front of its exp / rcp chains -- xform_act applies silu and stores.  Same operations, same bits.
+  auto xform_lin = [&](const vec_t& raw, const vec_t& rawl, float lw, const char* sAdst, float* f) {
+    const char* cf = sAdst + CHB + cpc * (VE / 2) * AROW;
+    f32x4 q[VE / 2];
+#if IVID_EXP & 2   // timing only: no coefficient reads
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) q[k] = f32x4{1.f, 1.f, lw, lw};
+    (void)cf;
+#else
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) q[k] = *(const f32x4*)(cf + k * AROW);
+#endif
+    vec_to_f32<T>(raw, f);
+    if constexpr (LOIN) {
+      float l[VE];
+      vec_to_f32<T>(rawl, l);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) f[e] = __builtin_fmaf(l[e], lw, f[e]);
+    }
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) {
+      const f32x2 v = f32x2{f[2 * k], f[2 * k + 1]} * f32x2{q[k][0], q[k][1]} + f32x2{q[k][2], q[k][3]};
+      f[2 * k] = v[0];
+      f[2 * k + 1] = v[1];
+    }
+  };
+  auto xform_act = [&](int j, float* f, char* sAdst) {
+#if IVID_EXP & 1   // timing only: no silu
+    store_piece(j, f, sAdst);
+    return;
+#endif
+    f32x2 v[VE / 2], d[VE / 2];
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) {
+      v[k] = f32x2{f[2 * k], f[2 * k + 1]};
+      const f32x2 t = v[k] * -1.4426950408889634f;
+      d[k] = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    }
+#pragma unroll
+    for (int k = 0; k < VE / 2; ++k) {
+      d[k] = d[k] + 1.0f;
+      const f32x2 y = v[k] * f32x2{__builtin_amdgcn_rcpf(d[k][0]), __builtin_amdgcn_rcpf(d[k][1])};
+      f[2 * k] = y[0];
+      f[2 * k + 1] = y[1];
     }
     store_piece(j, f, sAdst);
   };
@@ -387,7 +444,11 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
           if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else wait_vmcnt0();
+#if IVID_EXP & 64
+        asm volatile("s_barrier" ::: "memory");   // barrier X (every LDS read of the MFMA phase has been consumed by then)
+#else
         __syncthreads();  // barrier X
+#endif
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
@@ -406,8 +467,13 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
         if (grp == 1 && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
+#if IVID_EXP & 4   // timing only: no raw halo loads in the loop
+          asm volatile("" : "+v"(raw[tap & 1]));
+          if constexpr (LOIN) asm volatile("" : "+v"(rawl[tap & 1]));
+#else
           raw[tap & 1] = load_piece(tap, csn);
           if constexpr (LOIN) rawl[tap & 1] = load_piece_lo(tap, csn);
+#endif
         }
         const char* const ap = aptr + (g * HW_ + t) * AROW;   // fragment mi adds mi halo rows of pixels
         if constexpr (IsSplit<T>::value) {
@@ -482,19 +548,35 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-        // ---- fragments of k-piece 0 ----
+        // ---- halo transform, first half; fragments of k-piece 0; second half ----
         vec_t a[MI], b[NI];
+        float xf[VE];
+        if (do_store) {
+          xform_lin(cur, curl, csn.lw, sAn, xf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) a[mi] = *(const vec_t*)(ap + mi * HW_ * AROW);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB0 + b_off + ni * (32 * CHB));
-        if (do_store) xform_store(tap - 2, cur, curl, csn.lw, sAn);
+        if (do_store) {
+          __builtin_amdgcn_sched_barrier(0);
+          xform_act(tap - 2, xf, sAn);
+        }
         // ---------- phase 2 ("mma"): this group owns the matrix pipe, the other group is in its phase 1 ----------
         if (do_load) {
           if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else wait_vmcnt0();
+#if IVID_EXP & 32
+        // Barrier Y WITHOUT the fence of __syncthreads(): the fence waits lgkmcnt(0), i.e. for the LDS store of the halo piece
+        // this wave issued last -- data nobody reads before the next chunk (>= 2 barriers away; the LDS executes a wave's
+        // operations in order, so the fragment reads the wave consumes in its MFMA phase prove the store done long before).
+        // The fragment reads themselves are waited for by the compiler's counted lgkmcnt in front of the first MFMA.
+        asm volatile("s_barrier" ::: "memory");
+#else
         __syncthreads();  // barrier Y
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -660,121 +742,129 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   }
 
   // ---------------- epilogue (as conv_igemm: per-wave slab -> 16-byte NHWC stores, bias, residual, GN partials) ----------------
+  // Round 6: the passes of a fragment are ONE straight-line instantiation per (residual kind, full / partial channel range),
+  // picked by a wave-uniform branch per fragment.  Carried as runtime branches inside the pass loop (residual mode, lo planes present or not, `channel < Cout`), the
+  // same code made the compiler's wait-count pass give up at every join and wait vmcnt(0) -- for the residual loads AND, because
+  // vmcnt retires in issue order and counts stores, for the acknowledgement of every output store issued before: 17 us per tile
+  // with a hi + lo residual against 8.6 without one.  Residual loads now run ONE fragment ahead -- requested in front of the previous fragment's output stores -- with exact counted waits.
   TL_STAMP(5);
   constexpr int LDC = WTN + 4;
   constexpr int LPR = WTN / VE, RPP = 64 / LPR, NPS = 32 / RPP;   // lanes per slab row, rows per pass, passes per fragment
   const int Cout = p.Cout;
   const int nbase = n0 + wn * WTN;
   const int lr = lane / LPR, lc = (lane - lr * LPR) * VE;
-  // Residual (same size / nearest-x2 of a half-size tensor): ALL loads of the wave's four fragments are issued here, in
-  // one batch, before the accumulators start moving -- one HBM latency for the whole epilogue instead of one per
-  // fragment (the per-fragment form exposed it four times: a same-size residual cost ~20 % on the 128^2 256->256 layers).
-  // The fragment registers of the main loop are dead by now, so the 8 pieces fit.
-  // (fp32 storage: 8 pieces per lane and fragment -- batching four fragments would spill, so those modes prefetch per fragment)
-  constexpr int HB = NPS <= 2 ? MI : 1;   // fragments whose residual loads are batched
-  vec_t rres[HB][NPS];
-  vec_t rres_lo[LO ? HB : 1][LO ? NPS : 1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads of the last K-step done
+  // The accumulators leave through code every form shares (slab writes); only the four passes of a fragment -- slab reads,
+  // bias, residual, rounding, stores, statistics: nothing that touches an accumulator -- exist once per form
+  // (RES: 0 no residual, 1 same-size or nearest-x2 residual = res_mode 1 / 2, 3 the 2x2 average pool of a (2H, 2W) tensor;
+  // FULL: all 64 output channels of this wave exist, no lane guard -- Cout % 64 == 0 is every layer of the models).  A dispatch
+  // over whole epilogues, with 128 live accumulators flowing into six blocks, made the register allocator spill them.
+  // (global address space said explicitly: with the pointers selected / offset as below the compiler otherwise falls back to FLAT
+  // operations, which also count on lgkmcnt and serialise the slab reads behind them)
+  auto gl = [](const char* q, size_t ub, unsigned vo) { return (const __attribute__((address_space(1))) char*)q + ub + vo; };
+  auto gs = [](char* q, size_t ub, unsigned vo) { return (__attribute__((address_space(1))) char*)q + ub + vo; };
+  typedef const __attribute__((address_space(1))) vec_t gvec_c;
+  typedef __attribute__((address_space(1))) vec_t gvec;
+  typedef __attribute__((address_space(1))) f16x4 gf16x4;
+  const int n = nbase + lc;                    // this lane's first output channel: the same 16-byte piece in every pass
+  const bool full = nbase + WTN <= Cout;       // wave-uniform
+  const bool lane_on = n < Cout;
+  const int rk = (p.res_mode == 1 || p.res_mode == 2) ? 1 : p.res_mode;
+  // a missing lo plane of the residual is replaced by the hi plane with weight 0: the loads stay unconditional
   const bool res_has_lo = LO && p.res_lo != nullptr;
   const bool out_has_lo = LO && p.out_lo != nullptr;
-  auto load_res = [&](int mi) {
+  const float rlw = res_has_lo ? 1.f : 0.f, olw = out_has_lo ? 1.f : 0.f;
+  // every address = a wave-uniform 64-bit base (scalar registers) + ONE of three 32-bit lane offsets: the unrolled passes then
+  // need no address registers of their own
+  const int nl = lane_on ? n : 0;
+  const unsigned vo_same = (unsigned)((lr * Cout + nl) * (int)sizeof(T));          // pixel lr of a pass, same-size tensor
+  const unsigned vo_half = (unsigned)(((lr >> 1) * Cout + nl) * (int)sizeof(T));   // ... of a half-size tensor (RPP is even)
+  const unsigned vo_dbl = (unsigned)((2 * lr * Cout + nl) * (int)sizeof(T));       // ... of a double-size tensor
+  const bool res_up = p.res_mode == 2;
+  constexpr int HB = 2;                        // residual buffers: the fragment being consumed + the one in flight
+  vec_t rres[HB][NPS];
+  vec_t rres_lo[LO ? HB : 1][LO ? NPS : 1];
+  auto load_res = [&](int mi) {                // residual (kind 1) of fragment mi
     const int y = y0 + wm * 4 + mi;
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-      const int xr = x0 + ps * RPP + lr;
-      const size_t pix = p.res_mode == 1 ? ((size_t)img * p.H + y) * p.W + xr
-                                         : ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (xr >> 1);
-      rres[mi % HB][ps] = *(const vec_t*)(p.res + (pix * Cout + nbase + lc) * sizeof(T));
+      const int xu = x0 + ps * RPP;            // wave-uniform
+      const size_t pixu = res_up ? ((size_t)img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (xu >> 1) : ((size_t)img * p.H + y) * p.W + xu;
+      const size_t ub = pixu * Cout * sizeof(T);
+      const unsigned vo = res_up ? vo_half : vo_same;
+      rres[mi % HB][ps] = *(gvec_c*)gl(p.res, ub, vo);
       if constexpr (LO) {
-        if (res_has_lo) rres_lo[mi % HB][ps] = *(const vec_t*)(p.res_lo + (pix * Cout + nbase + lc) * sizeof(T));
+        rres_lo[mi % HB][ps] = *(gvec_c*)gl(res_has_lo ? p.res_lo : p.res, ub, vo);
       }
     }
   };
-  const bool res12 = (p.res_mode == 1 || p.res_mode == 2) && nbase + lc < Cout;
-  if (HB == MI && res12) {
+  if (rk == 1) load_res(0);
+  float bv[VE];              // this lane's bias values
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) load_res(mi);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads of the last K-step done (DMA is waited below)
-  {
-    // every LDS-DMA of the main loop / skip phase has landed long ago (the last stage was consumed); only the residual
-    // loads may be in flight, and they must stay in flight across this barrier
-    __builtin_amdgcn_s_barrier();
-  }
+  for (int e = 0; e < VE; ++e) bv[e] = (p.bias && lane_on) ? p.bias[n + e] : 0.f;
+  // every LDS-DMA of the main loop / skip phase has landed long ago (the last stage was consumed); only the residual / bias
+  // loads are in flight, and they stay in flight across this barrier
+  __builtin_amdgcn_s_barrier();
   float* slab = (float*)smem + wave * (32 * LDC);
   float st_s[VE], st_q[VE];  // GroupNorm partial statistics of this wave's 128 pixels (fused gn_partial)
-  float bv[VE];              // this lane's bias values: the same 16-byte channel piece in every pass
-  {
-    const int nb = nbase + lc;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) bv[e] = (p.bias && nb < Cout) ? p.bias[nb + e] : 0.f;
-  }
+  for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
+  auto passes = [&](const int mi, auto res_c, auto full_c) {
+    constexpr int RES = decltype(res_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
+    const bool on = FULL || lane_on;
+    const int y = y0 + wm * 4 + mi;                            // this fragment = image row y, pixels x0 .. x0+31
+    const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;   // wave-uniform
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int y = y0 + wm * 4 + mi;                        // this fragment = image row y, pixels x0 .. x0+31
-    const size_t mbase = ((size_t)img * p.H + y) * p.W + x0;
-    if (HB == 1 && res12) load_res(mi);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
-      }
-    wave_lds_sync();  // the slab is private to this wave
-    if (mi == 0) {
-#pragma unroll
-      for (int e = 0; e < VE; ++e) st_s[e] = st_q[e] = 0.f;
-    }
-#pragma unroll
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
+    for (int ps = 0; ps < NPS; ++ps) {
       const int row = ps * RPP + lr;
-      const size_t m = mbase + row;
-      const int n = nbase + lc;
-      if (n < Cout) {
-        float v[VE];
+      const size_t ob = (mbase + ps * RPP) * Cout * sizeof(T);   // wave-uniform byte offset of the pass in a same-size tensor
+      float v[VE];
 #pragma unroll
-        for (int e = 0; e < VE; e += 4) {
-          const f32x4 t = *(const f32x4*)(slab + row * LDC + lc + e);
-          v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+      for (int e = 0; e < VE; e += 4) {
+        const f32x4 q = *(const f32x4*)(slab + row * LDC + lc + e);
+        v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] += bv[e];
+      if constexpr (RES == 1) {
+        float rv[VE];
+        vec_to_f32<T>(rres[mi % HB][ps], rv);
+        if constexpr (LO) {
+          float rl[VE];
+          vec_to_f32<T>(rres_lo[mi % HB][ps], rl);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) rv[e] = __builtin_fmaf(rl[e], rlw, rv[e]);   // (= rv + rl, or rv without a lo plane)
         }
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[e] += bv[e];
-        if (p.res_mode == 1 || p.res_mode == 2) {
+        for (int e = 0; e < VE; ++e) v[e] += rv[e];
+      } else if constexpr (RES == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)
+        float sacc[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) sacc[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const size_t pixu = ((size_t)img * (p.H << 1) + 2 * y + (d >> 1)) * (p.W << 1) + 2 * (x0 + ps * RPP) + (d & 1);
+          const size_t ub = pixu * Cout * sizeof(T);
           float rv[VE];
-          vec_to_f32<T>(rres[mi % HB][ps], rv);
+          { const vec_t rq = *(gvec_c*)gl(p.res, ub, vo_dbl); vec_to_f32<T>(rq, rv); }
+#pragma unroll
+          for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
           if constexpr (LO) {
             if (res_has_lo) {
-              float rl[VE];
-              vec_to_f32<T>(rres_lo[mi % HB][ps], rl);
+              { const vec_t rq = *(gvec_c*)gl(p.res_lo, ub, vo_dbl); vec_to_f32<T>(rq, rv); }
 #pragma unroll
-              for (int e = 0; e < VE; ++e) rv[e] += rl[e];
+              for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
             }
           }
-#pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] += rv[e];
-        } else if (p.res_mode == 3) {  // residual source is (2H, 2W): 2x2 average pool (Downsample2d on the skip path)
-          float sacc[VE];
-#pragma unroll
-          for (int e = 0; e < VE; ++e) sacc[e] = 0.f;
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const size_t pix = ((size_t)img * (p.H << 1) + 2 * y + (d >> 1)) * (p.W << 1) + 2 * (x0 + row) + (d & 1);
-            float rv[VE];
-            vec_to_f32<T>(*(const vec_t*)(p.res + (pix * Cout + n) * sizeof(T)), rv);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
-            if constexpr (LO) {
-              if (res_has_lo) {
-                vec_to_f32<T>(*(const vec_t*)(p.res_lo + (pix * Cout + n) * sizeof(T)), rv);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) sacc[e] += rv[e];
-              }
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
         }
-        const vec_t ov = f32_to_vec<T>(v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] += 0.25f * sacc[e];
+      }
+      const vec_t ov = f32_to_vec<T>(v);
+      float sv[VE];
+      vec_to_f32<T>(ov, sv);
+      if (on) {
         if constexpr (O16) {   // fp32 storage (VE = 4): the fp16 twin of the value, 8-byte stores
           f16x4 th, tl;
 #pragma unroll
@@ -782,54 +872,72 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
             th[e] = (_Float16)v[e];
             tl[e] = (_Float16)(v[e] - (float)th[e]);
           }
-          *(f16x4*)(p.out16_hi + (m * Cout + n) * 2) = th;
-          *(f16x4*)(p.out16_lo + (m * Cout + n) * 2) = tl;
-          if (p.out) *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+          *(gf16x4*)gs(p.out16_hi, ob / 2, vo_same / 2) = th;   // (fp32 storage: the fp16 planes are half the bytes)
+          *(gf16x4*)gs(p.out16_lo, ob / 2, vo_same / 2) = tl;
+          if (p.out) *(gvec*)gs(p.out, ob, vo_same) = ov;
         } else {
-          *(vec_t*)(p.out + (m * Cout + n) * sizeof(T)) = ov;
+          *(gvec*)gs(p.out, ob, vo_same) = ov;
         }
-        float sv[VE];
-        vec_to_f32<T>(ov, sv);
-        if constexpr (LO) {
-          if (out_has_lo) {   // lo plane: what the 16-bit rounding dropped; the statistics describe hi + lo
-            float lv[VE];
+      }
+      if constexpr (LO) {   // lo plane: what the 16-bit rounding dropped; the statistics describe hi + lo
+        // (computed unconditionally, weight 0 without an output lo plane: a branch around VALUE computations inside the unrolled
+        // passes lets the compiler sink the statistics sums behind the last pass, with every pass's values spilled)
+        float lv[VE];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) lv[e] = v[e] - sv[e];
-            const vec_t ol = f32_to_vec<T>(lv);
-            *(vec_t*)(p.out_lo + (m * Cout + n) * sizeof(T)) = ol;
-            vec_to_f32<T>(ol, lv);
+        for (int e = 0; e < VE; ++e) lv[e] = v[e] - sv[e];
+        const vec_t ol = f32_to_vec<T>(lv);
+        if (out_has_lo && on) *(gvec*)gs(p.out_lo, ob, vo_same) = ol;
+        vec_to_f32<T>(ol, lv);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) sv[e] += lv[e];
-          }
-        }
-        if (p.stats) {
+        for (int e = 0; e < VE; ++e) sv[e] = __builtin_fmaf(lv[e], olw, sv[e]);
+      }
 #pragma unroll
-          for (int e = 0; e < VE; ++e) {
-            st_s[e] += sv[e];
-            st_q[e] = __builtin_fmaf(sv[e], sv[e], st_q[e]);
-          }
-        }
+      for (int e = 0; e < VE; ++e) {
+        st_s[e] += sv[e];
+        st_q[e] = __builtin_fmaf(sv[e], sv[e], st_q[e]);
       }
     }
-    if (p.stats && mi == MI - 1) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
+  };
 #pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-          st_s[e] += __shfl_xor(st_s[e], off);
-          st_q[e] += __shfl_xor(st_q[e], off);
-        }
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        slab[row * LDC + ni * 32 + frow] = acc[mi][ni][r];
       }
-      const int n = nbase + lc;
-      if (lr == 0 && n < Cout) {
-        // block id inside the image: (4-row band) x (32-pixel column strip), the same partition in both tile shapes
-        const size_t blk = (size_t)img * (p.H / 4) * p.tiles_x + (size_t)(ty * (TH / 4) + wm) * p.tiles_x + tx;
-        float* sp = p.stats + (blk * Cout + n) * 2;
-#pragma unroll
-        for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
-      }
+    // the next fragment's residual is requested as soon as this fragment's accumulators are dead -- and in front of this
+    // fragment's output stores in the wave's in-order memory queue
+    if (rk == 1 && mi + 1 < MI) load_res(mi + 1);
+    wave_lds_sync();  // the slab is private to this wave
+    if (full) {
+      if (rk == 0) passes(mi, std::integral_constant<int, 0>{}, std::true_type{});
+      else if (rk == 1) passes(mi, std::integral_constant<int, 1>{}, std::true_type{});
+      else passes(mi, std::integral_constant<int, 3>{}, std::true_type{});
+    } else {
+      if (rk == 0) passes(mi, std::integral_constant<int, 0>{}, std::false_type{});
+      else if (rk == 1) passes(mi, std::integral_constant<int, 1>{}, std::false_type{});
+      else passes(mi, std::integral_constant<int, 3>{}, std::false_type{});
     }
     wave_lds_sync();  // the slab is private to this wave
+  }
+  if (p.stats) {  // one partial per wave: 4 image rows x 32 pixels = a 128-pixel block
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        st_s[e] += __shfl_xor(st_s[e], off);
+        st_q[e] += __shfl_xor(st_q[e], off);
+      }
+    }
+    if (lr == 0 && lane_on) {
+      // block id inside the image: (4-row band) x (32-pixel column strip), the same partition in both tile shapes
+      const size_t blk = (size_t)img * (p.H / 4) * p.tiles_x + (size_t)(ty * (TH / 4) + wm) * p.tiles_x + tx;
+      float* sp = p.stats + (blk * Cout + n) * 2;
+#pragma unroll
+      for (int e = 0; e < VE; e += 2) *(f32x4*)(sp + e * 2) = f32x4{st_s[e], st_q[e], st_s[e + 1], st_q[e + 1]};
+    }
   }
 #ifdef IVID_DEV_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of this wave retired
