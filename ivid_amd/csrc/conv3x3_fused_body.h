@@ -2,9 +2,6 @@
 // shapes (FusedShape<WIDE>), included by conv3x3_fused.hip (WIDE: Cout > 128, the C entry points) and conv3x3_fused128.hip
 // (NARROW: Cout <= 128).  Read the header comment of conv3x3_fused.hip first.
 #pragma once
-#ifndef IVID_EXP
-#define IVID_EXP 0   // development builds only (scripts/r6/build_exp.py): bit mask of experimental / timing-only code paths
-#endif
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -219,11 +216,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     } else {
       u32x4 ob = __builtin_bit_cast(u32x4, f32_to_vec<T>(f));
       ob &= keep;
-#if IVID_EXP & 8   // timing only: no LDS store of the transformed piece
-      asm volatile("" :: "v"(ob));
-#else
       if (j < PIECES - 1 || act5) *(u32x4*)(sAdst + st_lds + j * PPP * AROW) = ob;
-#endif
     }
   };
   // y = silu(x*a + b) (exactly silu_f's operations, two channels per packed instruction)
@@ -258,14 +251,8 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
   auto xform_lin = [&](const vec_t& raw, const vec_t& rawl, float lw, const char* sAdst, float* f) {
     const char* cf = sAdst + CHB + cpc * (VE / 2) * AROW;
     f32x4 q[VE / 2];
-#if IVID_EXP & 2   // timing only: no coefficient reads
-#pragma unroll
-    for (int k = 0; k < VE / 2; ++k) q[k] = f32x4{1.f, 1.f, lw, lw};
-    (void)cf;
-#else
 #pragma unroll
     for (int k = 0; k < VE / 2; ++k) q[k] = *(const f32x4*)(cf + k * AROW);
-#endif
     vec_to_f32<T>(raw, f);
     if constexpr (LOIN) {
       float l[VE];
@@ -281,10 +268,6 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     }
   };
   auto xform_act = [&](int j, float* f, char* sAdst) {
-#if IVID_EXP & 1   // timing only: no silu
-    store_piece(j, f, sAdst);
-    return;
-#endif
     f32x2 v[VE / 2], d[VE / 2];
 #pragma unroll
     for (int k = 0; k < VE / 2; ++k) {
@@ -444,11 +427,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
           if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else wait_vmcnt0();
-#if IVID_EXP & 64
-        asm volatile("s_barrier" ::: "memory");   // barrier X (every LDS read of the MFMA phase has been consumed by then)
-#else
         __syncthreads();  // barrier X
-#endif
         const int par = (ch + tap) & 1;  // parity of the running K-step index 9 ch + tap: selects the weight stage
         const int b_off = par * B_BYTES + b_addr0;
         // consume BEFORE issuing (the compiler counts only its own loads, not the asm LDS-DMA: a use placed after an
@@ -467,13 +446,8 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
         if (grp == 1 && (MORE || tap < 8)) issue_b_g1(par ^ 1, tap == 8 ? ch + 1 : ch, tap == 8 ? 0 : tap + 1);
         if (do_load) {
           if (tap == 0) abq = ab_load(ch + 1);
-#if IVID_EXP & 4   // timing only: no raw halo loads in the loop
-          asm volatile("" : "+v"(raw[tap & 1]));
-          if constexpr (LOIN) asm volatile("" : "+v"(rawl[tap & 1]));
-#else
           raw[tap & 1] = load_piece(tap, csn);
           if constexpr (LOIN) rawl[tap & 1] = load_piece_lo(tap, csn);
-#endif
         }
         const char* const ap = aptr + (g * HW_ + t) * AROW;   // fragment mi adds mi halo rows of pixels
         if constexpr (IsSplit<T>::value) {
@@ -568,15 +542,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
           if constexpr (LOIN) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else wait_vmcnt0();
-#if IVID_EXP & 32
-        // Barrier Y WITHOUT the fence of __syncthreads(): the fence waits lgkmcnt(0), i.e. for the LDS store of the halo piece
-        // this wave issued last -- data nobody reads before the next chunk (>= 2 barriers away; the LDS executes a wave's
-        // operations in order, so the fragment reads the wave consumes in its MFMA phase prove the store done long before).
-        // The fragment reads themselves are waited for by the compiler's counted lgkmcnt in front of the first MFMA.
-        asm volatile("s_barrier" ::: "memory");
-#else
         __syncthreads();  // barrier Y
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
