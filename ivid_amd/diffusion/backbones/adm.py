@@ -25,7 +25,7 @@ HIP launch plan (plan.py) on weights repacked once per precision:
                         island (fp32 storage, bf16 hi + lo operands, 3 MFMAs per product).  Measured on the representative
                         forward set (q-sampled scenes, t in {0..999}): max 8.8e-4 (large) / 8.3e-4 (small), where fp16cx is
                         1.45e-3 and fp16c 1.66e-3 -- the fastest mode INSIDE the 1e-3 tolerance per forward (15 % slower than fp16cx)
-    precision "fp16sa": ADAPTIVE (round 4, the default of `use_fp16` since round 5): fp16s for every forward nobody announced a timestep
+    precision "fp16sa": ADAPTIVE (round 4; opt-in again since round 6): fp16s for every forward nobody announced a timestep
                         for and for announced timesteps t < 150; fp16s WITHOUT its island ("fp16cs") for forwards a sampler announced
                         with t >= 150 (note_timestep; the samplers of this package do it) -- every row of every representative
                         forward set is inside the tolerance in the mode its timestep selects (tests/test_adaptive_gpu.py); 8 % faster
@@ -33,12 +33,17 @@ HIP launch plan (plan.py) on weights repacked once per precision:
     precision "fp16sa3": fp16sa + a third tier: plain fp16cx (no split skip convolutions either) from t >= 500.  Inside the tolerance
                         there on the two UNCONDITIONAL 128^2 backbones (8.4e-4 / 8.8e-4), not with margin on the conditional / SR
                         ones (9.3e-4 / 9.6e-4): opt-in, and what bench.py's headline rule may pick after checking every row in the run
-    precision "fp16sx": the STRICT ladder (round 5): bf16x3 below t = 250, fp16s up to 500, fp16cs above -- keeps BOTH parity metrics of
-                        SURVEY.md 8(c) (rel-L2 and max-abs / |ref|_inf; the second is ~1.6 x the first on these outputs) under 1e-3
-                        on every row of every forward set; an unannounced forward runs bf16x3
+    precision "fp16sx": the STRICT ladder (round 5; what `use_fp16` selects since round 6): bf16x3 below t = 250, fp16s up to 500,
+                        fp16cs above -- keeps BOTH parity metrics of SURVEY.md 8(c) (rel-L2 and max-abs / |ref|_inf; the second is
+                        ~1.6 x the first on these outputs) under 1e-3 on every row of every forward set, with headroom (7.0e-4 / 7.5e-4);
+                        an unannounced forward runs bf16x3
+    Every ladder also has the GUIDANCE-AWARE tier (round 6, _lib.GUIDED_*): a forward announced with a guidance strength s,
+    1 + 2 s > 3, at a timestep >= 990 (the pure-noise first step(s) of a chain, where (1 + s) eps_c - s eps_u amplifies the two
+    branches' rounding 1.3 - 1.8e-3 deep in the 16-bit rungs) runs bf16x3.
     precision "bf16"  : bf16 storage + bf16 MFMA (perf mode; same rate as fp16, 3 fewer mantissa bits, fp32 range)
-`use_fp16=True` configs select "fp16sa" (the reference's fp16 torso, made to meet the fp32 tolerance on every input; a direct call
-without an announced timestep runs plain fp16s); override with the extra kwarg `precision=` or the environment variable IVID_PRECISION.  There is no CPU path: calling forward
+`use_fp16=True` configs select "fp16sx" (the reference's fp16 torso, made to meet the fp32 tolerance in both metrics on every input;
+a direct call without an announced timestep runs bf16x3); override with the extra kwarg `precision=` or the environment variable
+IVID_PRECISION -- the faster ladders "fp16sa" / "fp16sa3" hold the rel-L2 metric only and sit close to the bar.  There is no CPU path: calling forward
 without a GPU / without the built library raises.
 """
 import math
@@ -101,7 +106,8 @@ class AdmUnet2d(nn.Module):
             # layers in split precision ("fp16s"): inside the 1e-3 tolerance of the fp32 path on the representative forward set
             # (8.8e-4 max), which a plain fp16 torso -- the reference's own included -- is not (up to 2.1e-3 there)
             # since round 5 the adaptive form of that mode: the samplers announce their timestep, forwards at t >= 150 drop the island
-            precision = "fp16sa" if use_fp16 else "fp32"
+            # round 6: the strict ladder (_lib.DEFAULT_FP16: both parity metrics with headroom); the faster ladders are opt-in
+            precision = _lib.DEFAULT_FP16 if use_fp16 else "fp32"
         self.set_precision(precision)
         self.use_graph = os.environ.get("IVID_NO_GRAPH", "0") != "1"
         self.max_plans = int(os.environ.get("IVID_MAX_PLANS", "16"))
@@ -148,17 +154,38 @@ class AdmUnet2d(nn.Module):
         # announced a timestep for, tier k the forwards announced (note_timestep) with t >= its t_min.  IVID_ADAPTIVE_T /
         # IVID_ADAPTIVE_T2 move the thresholds of tiers 1 / 2.
         tiers = list(_lib.ADAPTIVE.get(precision, ((precision, 0),)))
-        for k, env in ((1, "IVID_ADAPTIVE_T"), (2, "IVID_ADAPTIVE_T2")):
-            if k < len(tiers) and env in os.environ:
+        for k in range(1, len(tiers)):      # IVID_ADAPTIVE_T / _T2 / _TS move the threshold of the rung they name, in any ladder
+            env = _lib.THRESHOLD_ENV.get(tiers[k][0])
+            if env and env in os.environ:
                 tiers[k] = (tiers[k][0], int(os.environ[env]))
-        assert all(a[1] <= b[1] for a, b in zip(tiers, tiers[1:])), f"adaptive tiers must ascend in t: {tiers}"
+        if not all(a[1] <= b[1] for a, b in zip(tiers, tiers[1:])):
+            raise ValueError(f"precision mode {precision!r}: the tiers' timestep thresholds must ascend, got {tiers} "
+                             f"(environment overrides: {sorted(set(_lib.THRESHOLD_ENV.values()))})")
+        # the guidance-aware tier (_lib.GUIDED_*): one more plan set in the exact mode, for 16-bit ladders only; a ladder whose
+        # tier 0 is that mode already (fp16sx) re-uses it
         self._tiers = tiers
+        self._guided_tier = None            # index into _tier_modes; == len(_tiers) when the ladder itself has no such rung
+        self._tier_modes = [m for m, _ in tiers]
+        if precision in _lib.ADAPTIVE:
+            if _lib.GUIDED_MODE in self._tier_modes:
+                self._guided_tier = self._tier_modes.index(_lib.GUIDED_MODE)
+            else:
+                self._tier_modes.append(_lib.GUIDED_MODE)
+                self._guided_tier = len(self._tier_modes) - 1
         self._base_precision = tiers[0][0]
         self._high_t_precision = tiers[1][0] if len(tiers) > 1 else None     # (kept: tier 1 of the two-tier mode)
         self.adaptive_t = tiers[1][1] if len(tiers) > 1 else int(os.environ.get("IVID_ADAPTIVE_T", str(_lib.ISLAND_T)))
         self._t_hint = None
+        self._g_hint = None
         self._packed_tiers = {}
         self._plans = {}
+
+    def note_guidance(self, strength):
+        """The frameworks know the classifier-free-guidance strength of the forward they are about to issue (cfg_branches).  In an
+        adaptive precision mode a forward announced with BOTH a strength s, 1 + 2 s > _lib.GUIDED_AMP, and a timestep >=
+        _lib.GUIDED_T runs the exact split-precision plan (the guidance-aware tier, _lib.GUIDED_*); consumed by the next forward
+        like the timestep announcement.  No effect in any other mode."""
+        self._g_hint = None if strength is None else float(strength)
 
     def note_timestep(self, t):
         """The samplers know the (batch-uniform) timestep of the forward they are about to issue as a host integer; the backbone sees
@@ -171,24 +198,29 @@ class AdmUnet2d(nn.Module):
         unrelated forward).  No effect in any other mode."""
         self._t_hint = None if t is None else int(t)
 
-    def tier_of(self, t):
-        """Index of the tier a forward announced with timestep t runs in (0 for t = None)."""
+    def tier_of(self, t, strength=None):
+        """Index of the tier a forward announced with timestep t (and guidance strength) runs in (0 for t = None)."""
         if t is None:
             return 0
+        if (self._guided_tier is not None and strength is not None and 1.0 + 2.0 * strength > _lib.GUIDED_AMP
+                and t >= _lib.GUIDED_T):
+            return self._guided_tier
         return max(k for k, (_, tmin) in enumerate(self._tiers) if k == 0 or t >= tmin)
 
     def _take_tier(self):
         t, self._t_hint = self._t_hint, None
-        return self.tier_of(t)
+        g, self._g_hint = self._g_hint, None
+        return self.tier_of(t, g)
 
     def _take_high_t(self):
         return self._take_tier() >= 1
 
     def convert_to_fp16(self):
         """Reference API (adm.py:508-514): fp16 torso (fp16 MFMA operands, fp32 accumulate / GroupNorm / softmax), with the
-        residual trunk kept as hi + lo fp16 planes and the trunk-critical layers in split precision (precision "fp16sa" = fp16s,
-        minus its island for forwards a sampler announces with t >= 150; "fp16s" / "fp16c" / "fp16cx" / plain "fp16" remain selectable)."""
-        self.set_precision("fp16sa")
+        residual trunk kept as hi + lo fp16 planes and the trunk-critical layers in split precision -- as the strict ladder
+        _lib.DEFAULT_FP16 ("fp16sx": the exact split mode below t = 250, fp16s up to 500, fp16s without its island above; both
+        parity metrics under 1e-3 with headroom).  The faster ladders "fp16sa" / "fp16sa3" and the single rungs remain selectable."""
+        self.set_precision(_lib.DEFAULT_FP16)
 
     def convert_to_fp32(self):
         self.set_precision("fp32")
@@ -234,7 +266,7 @@ class AdmUnet2d(nn.Module):
         the island's bf16x3 layouts exist in tier 0 alone, the skip convolutions' lo parts in the fp16s / fp16cs tiers)."""
         tier = int(tier)
         if tier not in self._packed_tiers:
-            self._packed_tiers[tier] = self._pack(self._tiers[tier][0])
+            self._packed_tiers[tier] = self._pack(self._tier_modes[tier])
         return self._packed_tiers[tier]
 
     def plan(self, batch, stacked=False, high_t=False):
@@ -244,8 +276,9 @@ class AdmUnet2d(nn.Module):
         batches -- whose arenas are GBs each at bs 64 but fit side by side, while a stream of distinct large batch sizes cannot
         pile arenas up."""
         tier = int(high_t)                                          # True = tier 1 (the two-tier mode's high-t plan)
-        if tier >= len(self._tiers):
-            raise ValueError(f"precision mode {self.precision!r} has {len(self._tiers)} tier(s), tier {tier} requested")
+        if tier >= len(self._tier_modes):
+            raise ValueError(f"precision mode {self.precision!r} has {len(self._tier_modes)} tier(s) (the guidance-aware one "
+                             f"included), tier {tier} requested")
         key = (batch, stacked, tier) if tier else (batch, stacked)
         p = self._plans.pop(key, None)
         if p is None:
@@ -291,7 +324,7 @@ class AdmUnet2d(nn.Module):
         weights -- into an engine file (bytes; written to `path` if given) that `ivid_unet_load` runs WITHOUT Python
         (include/ivid_hip.h; examples/unet_engine_host.c; diffusion/backbones/engine.py for the layout).  `high_t`: the adaptive
         mode's plan for announced timesteps >= adaptive_t (a host that samples from C keeps both engines and picks per step)."""
-        if int(high_t) >= len(self._tiers):
+        if int(high_t) >= len(self._tier_modes):
             raise ValueError(f"precision mode {self.precision!r} has no high-t plan (only the adaptive modes {sorted(_lib.ADAPTIVE)} do)")
         blob = self.plan(batch, stacked, high_t).export_engine()
         if path is not None:
@@ -306,14 +339,16 @@ class AdmUnet2d(nn.Module):
         (ddim.py:157-158), and only the first step pays.  The record is a weak reference + the tensor's version counter, so an
         in-place edit or another tensor (also one that re-uses the address) is checked again."""
         ok = self._labels_ok
-        if ok is not None and ok[0]() is classes and ok[1] == classes._version:
+        # (inference-mode tensors track no version counter: reading `_version` raises -- they are validated on every call)
+        ver = None if classes.is_inference() else classes._version
+        if ver is not None and ok is not None and ok[0]() is classes and ok[1] == ver:
             return
         if classes.numel():
             lo, hi = int(classes.min()), int(classes.max())
             assert self.has_null_class or lo >= 0, "this model does not have a null class"
             if hi >= self.num_classes:
                 raise IndexError(f"class label {hi} out of range for num_classes = {self.num_classes}")
-        self._labels_ok = (weakref.ref(classes), classes._version)
+        self._labels_ok = None if ver is None else (weakref.ref(classes), ver)
 
     # ---- reference-compatible forward ----
     @torch.no_grad()

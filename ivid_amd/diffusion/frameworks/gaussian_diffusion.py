@@ -70,6 +70,8 @@ def cfg_branches(backbone, x, t, classes, strength):
         ec = backbone(x, t, classes)
         return (ec if strength == 0 else (1 + strength) * ec), None, 0.0
     if hasattr(backbone, "forward_cfg"):
+        if hasattr(backbone, "note_guidance"):      # the guidance-aware precision tier (AdmUnet2d.note_guidance)
+            backbone.note_guidance(strength)
         ec, eu = backbone.forward_cfg(x, t, classes)
         return ec, eu, float(strength)
     return backbone(x, t, classes), backbone(x, t, None), float(strength)

@@ -165,7 +165,7 @@ def main(argv=None):
     p.add_argument("--precision", type=str, default=None, help="fp32 | bf16x3 | fp16s (fp16 MFMA, compensated trunk, trunk-critical layers in split precision: within 1e-3 of fp32 on "
                         "every input) | fp16sa (adaptive: fp16s without its first-level island at timesteps >= 150: +10 %%) | fp16sa3 (+ plain fp16cx "
                         "from t >= 500: unconditional 128^2 backbones) | fp16sx (strict ladder: both parity metrics under 1e-3) | fp16cx | "
-                        "fp16c | fp16 | bf16; default: fp16sa if the config says use_fp16 else fp32")
+                        "fp16c | fp16 | bf16; default: fp16sx if the config says use_fp16 else fp32")
     # 128 -> 256 super-resolution of every generated view (BASELINE config 5).  Not in the reference CLI: the reference ships
     # the SR model and SuperResCFG but no inference driver for them (only SuperResTrainer.sample, trainers/superres.py:97-134)
     p.add_argument("--config_sr", type=str, default=None, help="e.g. configs/rgbd_imagenet_adm_256_128_small_sr.json")

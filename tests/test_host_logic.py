@@ -160,6 +160,25 @@ def test_unsupported_attention_geometry_is_refused_at_construction():
     AdmUnet2d(**C.MINI)
 
 
+def test_label_check_accepts_inference_mode_tensors():
+    """The once-per-tensor label validation reads the tensor's version counter; inference-mode tensors have none (reading
+    `_version` raises): they are validated on every call instead (round-5 review)."""
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    m = AdmUnet2d(**dict(C.MINI, num_classes=10))
+    with torch.inference_mode():
+        cls = torch.tensor([1, 2])
+    m._check_labels(cls)
+    m._check_labels(cls)
+    assert m._labels_ok is None
+    with torch.inference_mode():
+        bad = torch.tensor([1, 10])
+    with pytest.raises(IndexError):
+        m._check_labels(bad)
+    ok = torch.tensor([3, 4])
+    m._check_labels(ok)
+    assert m._labels_ok is not None and m._labels_ok[0]() is ok
+
+
 def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
     """AdmUnet2d.note_timestep (host logic): only "fp16sa" has a high-t mode; an announcement selects it from adaptive_t upwards, is
     consumed by ONE query, and IVID_ADAPTIVE_T moves the threshold."""
@@ -198,7 +217,36 @@ def test_adaptive_mode_bookkeeping_of_the_announced_timestep():
     finally:
         del os.environ["IVID_ADAPTIVE_T2"]
     with pytest.raises(ValueError):
-        AdmUnet2d(**C.MINI, precision="fp16sa").plan(1, False, high_t=2)     # refused before anything touches a device
+        AdmUnet2d(**C.MINI, precision="fp16sa").plan(1, False, high_t=3)     # refused before anything touches a device
+    with pytest.raises(ValueError):
+        AdmUnet2d(**C.MINI, precision="fp16s").plan(1, False, high_t=1)      # a single rung has no other tier
+    # the overrides name the RUNG whose threshold they move, in any ladder (IVID_ADAPTIVE_T: fp16cs, _T2: fp16cx, _TS: fp16s), and a
+    # ladder that no longer ascends is refused with a message instead of a bare assertion
+    os.environ["IVID_ADAPTIVE_T"] = "700"
+    try:
+        m.set_precision("fp16sx")
+        assert m._tiers == [("bf16x3", 0), ("fp16s", 250), ("fp16cs", 700)]
+        with pytest.raises(ValueError, match="ascend"):
+            m.set_precision("fp16sa3")                                       # fp16cs at 700 behind fp16cx at 500
+    finally:
+        del os.environ["IVID_ADAPTIVE_T"]
+    # the guidance-aware tier: a forward announced with strength s, 1 + 2 s > 3, at t >= 990 runs the exact mode -- tier 0 of the
+    # strict ladder, one more plan set of the others; consumed with the timestep; no effect on a single rung
+    from ivid_amd import _lib
+    m.set_precision("fp16sx")
+    assert m._guided_tier == 0 and m._tier_modes == ["bf16x3", "fp16s", "fp16cs"]
+    assert [m.tier_of(t, 3.0) for t in (None, 0, 600, 989, 990, 999)] == [0, 0, 2, 2, 0, 0]
+    assert [m.tier_of(t, 0.5) for t in (990, 999)] == [2, 2] and m.tier_of(999, 1.0) == 2 and m.tier_of(999, 1.01) == 0
+    m.set_precision("fp16sa3")
+    assert m._tiers == [("fp16s", 0), ("fp16cs", 150), ("fp16cx", 500)] and m._tier_modes[-1] == _lib.GUIDED_MODE == "bf16x3"
+    assert m.tier_of(999, 3.0) == 3 and m.tier_of(999, None) == 2 and m.tier_of(989, 3.0) == 2
+    m.note_timestep(999); m.note_guidance(3.0)
+    assert m._take_tier() == 3 and m._take_tier() == 0
+    m.note_guidance(3.0)                                                     # a strength without a timestep selects nothing
+    assert m._take_tier() == 0
+    m.set_precision("fp16s")
+    m.note_timestep(999); m.note_guidance(3.0)
+    assert m._guided_tier is None and m._take_tier() == 0
     # the samplers announce through the framework: backbones without note_timestep are left alone
     from ivid_amd.diffusion.samplers.utils import announce_timestep
 
@@ -245,10 +293,10 @@ def test_precision_names_and_reference_fp16_api():
     for name, code in (("IVID_F32", 0), ("IVID_BF16", 1), ("IVID_F16", 2), ("IVID_BF16X3", 3)):
         assert re.search(rf"#define {name} {code}\b", hdr)
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16sa" and m.dtype == torch.float16         # adm.py:333: the reference's attribute
-    assert m._base_precision == "fp16s"                                 # an unannounced forward runs the full mode
+    assert m.precision == _lib.DEFAULT_FP16 == "fp16sx" and m.dtype == torch.float16   # adm.py:333: the reference's attribute
+    assert m._base_precision == "bf16x3"                                # an unannounced forward runs the most accurate tier
     m.convert_to_fp32(); assert m.precision == "fp32"
-    m.convert_to_fp16(); assert m.precision == "fp16sa"
+    m.convert_to_fp16(); assert m.precision == "fp16sx"
     m.set_precision("bf16x3"); assert m.precision == "bf16x3"
     with pytest.raises(ValueError):
         m.set_precision("int8")
@@ -472,3 +520,33 @@ def test_command_line_help_renders(mod):
     assert r.returncode == 0 and "usage:" in r.stdout, r.stderr[-400:]
     if mod.endswith("sample"):
         assert "--precision" in r.stdout and "fp16s" in r.stdout
+
+
+def test_bench_unet_share_walks_the_real_schedules_and_refuses_an_inconsistent_share():
+    """bench.py --config c3 | c4 | c5: the UNet share of a batch is the sum over the steps of the REAL schedules, each timed in
+    the tier its announced timestep + guidance strength select (round 5 timed one unannounced forward -- the costliest tier --
+    for all of them, reported more UNet seconds than the batch took and clamped the share to 0).  Host logic only."""
+    import bench
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    from ivid_amd.diffusion.frameworks.utils import get_betas_by_name
+    m = AdmUnet2d(**C.MINI, precision="fp16sx")
+    fw = type("F", (), {"betas": get_betas_by_name("linear", 1000)})
+    # DDPM-1000 at strength 3.0: the 10 pure-noise steps in the guidance-aware tier (= tier 0 of the strict ladder), then fp16cs down
+    # to t = 500, fp16s down to 250, bf16x3 below
+    tiers = bench.schedule_tiers(m, fw, "ddpm", 1000, 3.0)
+    assert len(tiers) == 1000 and tiers[:10] == [0] * 10 and tiers[10] == 2 and tiers[-1] == 0
+    assert (tiers.count(0), tiers.count(1), tiers.count(2)) == (10 + 250, 250, 490)
+    # DDIM-50 (t = 999, 979, ..., 19): one guided step, then 24 / 13 / 12
+    tiers = bench.schedule_tiers(m, fw, "ddim", 50, 3.0)
+    assert tiers[0] == 0 and (tiers.count(0), tiers.count(1), tiers.count(2)) == (1 + 12, 13, 24)
+    assert bench.schedule_tiers(m, fw, "ddim", 50, 0.5)[0] == 2            # no amplification at strength 0.5
+    m.set_precision("fp16s")
+    assert set(bench.schedule_tiers(m, fw, "ddim", 50, 3.0)) == {0}        # a single rung has one tier
+    counts = {0: 13, 1: 13, 2: 24}
+    assert abs(bench.unet_seconds(counts, {0: 200.0, 1: 100.0, 2: 90.0}) - (13 * 0.2 + 13 * 0.1 + 24 * 0.09)) < 1e-12
+    with pytest.raises(ValueError):
+        bench.unet_seconds(counts, {0: 200.0, 1: 100.0})                   # a tier that serves steps must have been timed
+    assert abs(bench.share_outside(9.0, 0.5, 10.0) - 0.05) < 1e-12
+    assert bench.share_outside(10.2, 0.0, 10.0) < 0                        # timing noise of a loop that is all forwards: reported as is
+    with pytest.raises(ValueError):
+        bench.share_outside(56.3, 0.0, 51.9)                               # round 5's figures: refused, not clamped to 0

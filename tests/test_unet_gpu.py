@@ -136,18 +136,20 @@ def test_mini_forward_reduced_precision_modes(name, args, seed, precision):
 def test_use_fp16_config_selects_the_fp16_torso_like_the_reference():
     """adm.py:333,508-514: use_fp16 / convert_to_fp16() mean an fp16 torso (not bf16) -- here fp16 MFMA operands with the
     compensated trunk, split-precision skip convolutions and first encoder level (precision "fp16s": inside the 1e-3 tolerance
-    of the fp32 path on the representative forward set, which a plain fp16 torso -- the reference's own included -- is not), in
-    its adaptive form "fp16sa" since round 5 (a direct call without an announced timestep IS the fp16s forward)."""
+    of the fp32 path on the representative forward set, which a plain fp16 torso -- the reference's own included -- is not), as
+    the strict ladder "fp16sx" since round 6 (both parity metrics with headroom; a direct call without an announced timestep IS
+    the bf16x3 forward, an announced one at t >= 250 the fp16s forward)."""
+    from ivid_amd import _lib
     from ivid_amd.diffusion.backbones import AdmUnet2d
     m = AdmUnet2d(**dict(C.MINI, use_fp16=True))
-    assert m.precision == "fp16sa" and m._base_precision == "fp16s" and m.dtype == torch.float16
+    assert m.precision == _lib.DEFAULT_FP16 == "fp16sx" and m._base_precision == "bf16x3" and m.dtype == torch.float16
     m.convert_to_fp32()
     assert m.precision == "fp32"
     m.convert_to_fp16()
-    assert m.precision == "fp16sa"
+    assert m.precision == "fp16sx"
     m.load_state_dict(C.synth_weights(C.MINI, 1), strict=True)
     m = m.cuda().eval()
-    ms, _ = build(C.MINI, 1, "fp16s")
+    ms, _ = build(C.MINI, 1, "bf16x3")
     x, t, cls = C.seeded_randn(2, 2, 4, 32, 32).cuda(), torch.tensor([3, 3]).cuda(), torch.tensor([1, 2]).cuda()
     assert torch.equal(m(x, t, cls), ms(x, t, cls))
 
@@ -378,9 +380,11 @@ def test_teacher_forced_guided_eps_at_strength_3_on_the_chains_own_inputs(chain)
     (1 + 3) eps_c - 3 eps_u (classifier_free_guidance.py:39-42, inpaint_cfg.py:80-83) on the tensors the REFERENCE chain fed its
     backbone (tests/golden/make_golden_steps_s3.py: DDPM-250 + CFG 3.0 at t = 249 .. 0 of its 250-step schedule; InpaintCFG 3.0 +
     DDIM-50 on the scene conditioning at t = 999, 599, 99 -- the 10-channel input with that step's hole noise).  Strength 3 puts
-    1 + 2s = 7 on a forward's deviation: the exact modes (fp32, bf16x3) hold 1e-3 per step with two orders of margin, the 16-bit
-    modes hold it for the SAMPLES of these chains (tests below) but NOT for every single guided eps -- measured here, reported in
-    profiles/, stated in bench.py's c3 / c4 / c5 lines ("sample-level parity"); bf16x3 is the per-step-exact mode."""
+    1 + 2s = 7 on a forward's deviation: the exact modes (fp32, bf16x3) hold 1e-3 per step with two orders of margin; the 16-bit
+    RUNGS hold it for the SAMPLES of these chains (tests below) but not for the guided eps of the first, pure-noise step (1.3 -
+    1.8e-3 there, <= 1.3e-4 on every later recorded step).  Round 6: the LADDERS -- what `use_fp16` configs and configs 3 / 4 / 5
+    run -- are told the strength by the framework (cfg_branches -> note_guidance) and run that step in the exact mode (the
+    guidance-aware tier, _lib.GUIDED_*): every recorded step inside 1e-3."""
     g = C.load_golden(chain + "_steps")
     args, seed = (C.SMALL128_CFG, 5) if chain.startswith("smallcfg") else (C.MINI128_COND, 2)
     fw_T = 250 if chain.startswith("smallcfg") else 1000
@@ -398,14 +402,16 @@ def test_teacher_forced_guided_eps_at_strength_3_on_the_chains_own_inputs(chain)
             x = torch.from_numpy(g[f"in_step{k}"]).cuda()
             t = torch.full((x.shape[0],), int(g[f"t_step{k}"]), dtype=torch.long).cuda()
             m.note_timestep(equivalent_timestep(fwk, int(g[f"t_step{k}"])))        # what the samplers announce
+            m.note_guidance(3.0)                                                   # what cfg_branches announces
             ec, eu = m.forward_cfg(x, t, cls)
             errs[prec][f"t{int(g[f't_step{k}'])}"] = C.rel_l2((4.0 * ec - 3.0 * eu).cpu(), g[f"eps_step{k}"])
         G.report(f"teacher_forced_s3/{chain}_{prec}", **errs[prec])
     print(chain, "teacher-forced guided eps, strength 3.0:", {p: {k: "%.2e" % v for k, v in e.items()} for p, e in errs.items()})
     for prec in ("fp32", "bf16x3"):
         assert max(errs[prec].values()) < 1e-4, (prec, errs[prec])
-    for prec in ("fp16s", "fp16sa", "fp16sx"):      # bounded, not inside 1e-3 on every step: 7 x a forward's 3-9e-4
-        assert max(errs[prec].values()) < 4e-3, (prec, errs[prec])
+    for prec in ("fp16sx", "fp16sa"):               # the ladders: guidance-aware tier on the pure-noise step
+        assert max(errs[prec].values()) < 1e-3, (prec, errs[prec])
+    assert max(errs["fp16s"].values()) < 4e-3, errs["fp16s"]    # a single rung: bounded, not inside 1e-3 on the first step
     assert max(errs["fp16s"].values()) <= max(errs["fp16"].values())
 
 
