@@ -655,7 +655,9 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
     for (int c = 0; c < nv; ++c) {
       wait_vmcnt0();
       __syncthreads();  // the stages of step c landed for every wave; everyone finished reading the stages of step c-1
-      if (c + 1 < nv) issue_skip(c + 1);
+      // skewed issue (round 6, as in conv_igemm): the first wave group issues the next step's DMA in front of its MFMAs, its SIMD
+      // partners behind their first k-piece
+      if (grp == 0 && c + 1 < nv) issue_skip(c + 1);
       const int a_off = stage_a(c) * SA_BYTES + sa_addr0;
       const int b_off = stage_b(c) * B_BYTES + b_addr0;
       if constexpr (IsSplit<T>::value) {
@@ -663,6 +665,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
 #pragma unroll
         for (int sidx = 0; sidx < NSB; ++sidx) {
           const int so = sidx * 64;
+          if (sidx == NSB - 1 && grp == 1 && c + 1 < nv) issue_skip(c + 1);
           bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
@@ -693,6 +696,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs& p, const int tile) {
       for (int kk = 0; kk < KK; ++kk) {
         const int xo = (kk + 1) << 5;
         const bool pf = kk < KK - 1;
+        if (kk == (KK > 1 ? 1 : 0) && grp == 1 && c + 1 < nv) issue_skip(c + 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) MmaT<T>::run(a[mi], b[0], acc[mi][0]);
         if (pf) b[0] = *(const vec_t*)(sB0 + (b_off ^ xo));

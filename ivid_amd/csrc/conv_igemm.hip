@@ -203,6 +203,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     for (int ni = 0; ni < NI; ++ni) b[ni] = *(const vec_t*)(sB + b_off[ni] + ((piece ^ b_sw[ni]) << 4));
   };
 
+  // Skewed issue (round 6, 8-wave tiles): the waves of the workgroup's first half issue the next stage's LDS-DMA in front of
+  // their MFMAs, their SIMD partners (waves w + 4) behind their first k-piece -- one wave of every SIMD feeds the matrix pipe
+  // while the other one is in its issue block (8 DMA pieces = several hundred cycles of an in-order wave).  In lockstep both
+  // waves of a SIMD issued first and shared the pipe afterwards: 16^2 768 -> 768 0.377 -> 0.342 ms, 1792 -> 768 0.820 -> 0.764,
+  // 1024 -> 1024 0.553 -> 0.534 (same box; behind the second k-piece: -3 %, behind the third: -1 %, four-way stagger: 0).
+  // The stage being filled is free for the whole step (its last readers passed this step's barrier), so the position is a pure
+  // scheduling choice; the data is waited for in front of the next barrier as before.
+  const bool late = NT >= 512 && wave >= NT / 128;
   issue(0);
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt0();
@@ -231,10 +239,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
       };
       bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
       load_split(0, ah[0], al[0], bh[0], bl[0]);
-      if (kt + 1 < nk) issue((kt + 1) & 1);
+      if (!late && kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         if (sidx == 0) load_split(1, ah[1], al[1], bh[1], bl[1]);
+        if (sidx == 1 && late && kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -248,10 +257,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_igemm_kernel(const
     } else {
     vec_t a[2][MI], b[2][NI];
     load_frags(sA, sB, 0, a[0], b[0]);
-    if (kt + 1 < nk) issue((kt + 1) & 1);
+    if (!late && kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) load_frags(sA, sB, kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
+      if (kk == 1 && late && kt + 1 < nk) issue((kt + 1) & 1);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -51,10 +51,15 @@ if len(sys.argv) > 2 and sys.argv[1] == "--one":
         ab = torch.rand(n, cin, 2, device="cuda", generator=fresh()) + 0.5
         res = rn(n, h, h, cout).to(tdt); resl = (rn(n, h, h, cout) * 1e-3).to(tdt)
         out = torch.empty(n, h, h, cout, device="cuda", dtype=tdt); outl = torch.empty_like(out)
+        if any(f.endswith("skip") or f.endswith("sks") for f in forms):     # skip sources: cat(256, 256) -> cout (the 128^2 decoder blocks)
+            sk0, sk1 = rn(n, h, h, 256).to(tdt), rn(n, h, h, 256).to(tdt)
+            sk0l, sk1l = (rn(n, h, h, 256) * 1e-3).to(tdt), (rn(n, h, h, 256) * 1e-3).to(tdt)
+            skw = (rn(cout, 512) / 512 ** 0.5).to(tdt); skwl = (rn(cout, 512) * 1e-4).to(tdt)
         ntiles = n * (h // 8) * (h // 32)
         stats_buf = torch.zeros(n * (h // 4) * (h // 32) * cout * 2, device="cuda")
         for tag in forms:
             lo_in = tag.startswith("LOIN"); lo_out = tag.startswith("LO"); r = tag.endswith("res")
+            sk = tag.endswith("skip") or tag.endswith("sks"); sks = tag.endswith("sks")
             dbg = torch.zeros(ntiles * 8, dtype=torch.int64, device="cuda")
             if has_tl:
                 lib.ivid_dev_timeline(C.c_void_p(dbg.data_ptr()))
@@ -63,7 +68,15 @@ if len(sys.argv) > 2 and sys.argv[1] == "--one":
             for it in range(2 + reps):
                 if it == 2:
                     ev0.record(stream)
-                _lib.check(lib.ivid_conv3x3_gn_skip_c(_lib.F16, x0.data_ptr(), x0l.data_ptr() if lo_in else None, c0,
+                if sk:    # the ResBlock's 1x1 skip_connection on cat(sk0, sk1) folded in: plain (hi planes) or split (SKS: + lo planes, + lo weights)
+                    _lib.check(lib.ivid_conv3x3_gn_skip_s(_lib.F16, x0.data_ptr(), x0l.data_ptr() if lo_in else None, c0,
+                                                          x1.data_ptr() if c1 else None, x1l.data_ptr() if (c1 and lo_in) else None, c1, ab.data_ptr(), 0,
+                                                          w.data_ptr(), b.data_ptr(), out.data_ptr(), outl.data_ptr() if lo_out else None,
+                                                          None, None, 0, n, h, h, cout, stats_buf.data_ptr(),
+                                                          sk0.data_ptr(), sk0.shape[-1], sk1.data_ptr(), sk1.shape[-1], skw.data_ptr(),
+                                                          sk0l.data_ptr() if sks else None, sk1l.data_ptr() if sks else None, skwl.data_ptr() if sks else None, sp), "launch")
+                else:
+                    _lib.check(lib.ivid_conv3x3_gn_skip_c(_lib.F16, x0.data_ptr(), x0l.data_ptr() if lo_in else None, c0,
                                                       x1.data_ptr() if c1 else None, x1l.data_ptr() if (c1 and lo_in) else None, c1, ab.data_ptr(), 0,
                                                       w.data_ptr(), b.data_ptr(), out.data_ptr(), outl.data_ptr() if lo_out else None,
                                                       res.data_ptr() if r else None, resl.data_ptr() if (r and lo_out) else None, 1 if r else 0,
