@@ -360,6 +360,52 @@ int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const f
  * y[B,Cy,s,s] with align_corners=False] (fp32 NCHW), torch's upsample_bilinear2d arithmetic. */
 int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int Cy, int S, int s, void* stream);
 
+/* ---- the whole sampling loop as ONE call (SURVEY.md 8(b) `ivid_sample(handle, plan*, ...)`) ----
+ * DdimSampler.sample / DdpmSampler.sample (diffusion/samplers/ddim.py:150-163, ddpm.py:172-185) with the frameworks'
+ * model_inference inside (classifier_free_guidance.py:23-42; inpaint_cfg.py:24-49,51-83): per step [make_cond_inputs ->] one
+ * UNet program (hipGraph replay) -> the fused step kernel.  Everything is enqueued on `stream`; nothing synchronises and no
+ * host code runs between the steps, so a C host samples without Python and N ranks do not compete for host cores.
+ *   engines        : UNet programs with a bound boundary (ivid_unet_load, or a plan's program), all with the same boundary:
+ *                    B rows of x.  Output B rows: eps as is; 2B rows (a stacked classifier-free-guidance plan): rows [0,B) the
+ *                    conditional and [B,2B) the null-class branch, combined inside the step kernel with the coefficients'
+ *                    cfg_strength.  engine_of_step picks the program of step i (the precision tier of its timestep).
+ *   plan           : host tables, one entry per step in sampling order: the timestep the model is fed (ddim.py:74 / ddpm.py:118
+ *                    `t - 1`) and the step's coefficients (what DdimSampler._coef / DdpmSampler._coef compute, fp32 like the
+ *                    reference); hw = pixels of an image
+ *   classes        : device int64 [B] or NULL
+ *   cond           : NULL, or the tensors that stay constant over the loop (device fp32):
+ *                    y [B,4,HW], mask [B,1,HW], mask_rgb [B,1,HW] or NULL, hole_noise [n_steps][B,4,HW] (per step the rgb
+ *                    noise [B,3,HW] followed by the depth noise [B,1,HW], inpaint_cfg.py:36-45) -- y == NULL: the model is fed x_t;
+ *                    rgb [B,3,HW], rgb_mask, depth, depth_mask, convex [B,1,HW]: replace_rgb / replace_depth / constrain_depth of
+ *                    DdimSampler.sample_once (ddim.py:86-95), needed when a step's weight is >= 0
+ *   x              : device fp32 [B,4,HW]: x_T on entry, the sample on return (when the stream has drained)
+ *   step_noise     : device fp32 [n_steps][B,4,HW] or NULL when no step draws noise (DDIM with eta = 0)
+ *   x0             : NULL or device fp32 [B,4,HW]: pred_x_0 of the last step
+ *   scratch        : device memory of ivid_sample_scratch_bytes(...) bytes, owned by the caller, free for reuse when the
+ *                    stream has drained
+ *   stream         : as for ivid_unet_forward with use_graph = 1 -- the programs capture their hipGraph on it the second time
+ *                    they run, so it must be a created stream, not the legacy default stream
+ * The whole plan is validated before anything is enqueued.  Results are bit-identical to driving the same programs and step
+ * kernels from the host (tests/test_sample_loop_gpu.py). */
+#define IVID_SAMPLE_DDIM 0
+#define IVID_SAMPLE_DDPM 1
+typedef struct {
+  int kind;                  /* IVID_SAMPLE_DDIM: coef = ivid_ddim_coef[n_steps]; IVID_SAMPLE_DDPM: ivid_ddpm_coef[n_steps] */
+  int n_steps;
+  int hw;
+  const long long* t_model;  /* host [n_steps] */
+  const void* coef;          /* host [n_steps] */
+  const int* engine_of_step; /* host [n_steps] or NULL (= engines[0] for every step) */
+} ivid_sample_plan;
+typedef struct {
+  const float* y; const float* mask; const float* mask_rgb; const float* hole_noise;
+  const float* rgb; const float* rgb_mask; const float* depth; const float* depth_mask; const float* convex;
+} ivid_sample_cond;
+long long ivid_sample_scratch_bytes(void* const* engines, int n_engines, const ivid_sample_plan* plan, const ivid_sample_cond* cond);
+int ivid_sample(void* const* engines, int n_engines, const ivid_sample_plan* plan, const long long* classes,
+                const ivid_sample_cond* cond, float* x, const float* step_noise, float* x0, void* scratch,
+                long long scratch_bytes, void* stream);
+
 /* ---- RGBD depth-warp conditioning (replaces rgbd_3d + the moderngl/OpenGL renderer) ----
  * Step 1, per generated view: depth -> textured grid mesh with frustum skirt (rgbd_3d/utils.py:144-260
  * depth_to_mesh(padding='frustum', cal_normal=True), linearize_depth :38-58, unproject :89-110,

@@ -74,6 +74,17 @@ class DdpmCoef(C.Structure):
         "sqrt_recip_ac", "sqrt_recipm1_ac", "coef1", "coef2", "std", "cfg_strength")] + [("clip_denoised", C.c_int)]
 
 
+class SamplePlan(C.Structure):      # ivid_sample_plan
+    _fields_ = [("kind", C.c_int), ("n_steps", C.c_int), ("hw", C.c_int), ("t_model", C.POINTER(C.c_longlong)),
+                ("coef", C.c_void_p), ("engine_of_step", C.POINTER(C.c_int))]
+
+
+class SampleCond(C.Structure):      # ivid_sample_cond
+    _fields_ = [(n, C.c_void_p) for n in ("y", "mask", "mask_rgb", "hole_noise", "rgb", "rgb_mask", "depth", "depth_mask", "convex")]
+
+
+SAMPLE_DDIM, SAMPLE_DDPM = 0, 1
+
 # name -> (restype, argtypes); must list every symbol declared in include/ivid_hip.h
 SIGNATURES = {
     "ivid_last_error": (C.c_char_p, []),
@@ -128,6 +139,8 @@ SIGNATURES = {
     "ivid_copy": (i32, [vp, vp, i64, vp]),
     "ivid_nchw_to_nhwc": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_stem_im2col": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_sample_scratch_bytes": (i64, [vp, i32, C.POINTER(SamplePlan), C.POINTER(SampleCond)]),
+    "ivid_sample": (i32, [vp, i32, C.POINTER(SamplePlan), vp, C.POINTER(SampleCond), vp, vp, vp, vp, i64, vp]),
     "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ivid_ddpm_step": (i32, [vp, vp, vp, C.POINTER(DdpmCoef), vp, vp, vp, i32, i32, vp]),
     "ivid_inpaint_cond": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

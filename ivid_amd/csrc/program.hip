@@ -322,6 +322,114 @@ extern "C" int ivid_unet_info(void* handle, int* batch, int* has_classes, long l
   return 0;
 }
 
+// ---- the whole sampling loop as one call (include/ivid_hip.h: ivid_sample) ----
+namespace {
+__global__ void fill_i64_kernel(long long* dst, long long v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+struct SampleGeom { int B, HW, cin, rows; bool stacked; };
+// every program of the loop must have the same boundary: B rows of x with cin channels of HW pixels, B (plain) or 2B (both
+// guidance branches stacked) rows of 4 output channels
+int sample_geom(void* const* engines, int n_engines, int HW, SampleGeom* g) {
+  if (!engines || n_engines <= 0 || HW <= 0) return ivid_set_error("sample: no programs / bad image size", hipSuccess);
+  for (int k = 0; k < n_engines; ++k) {
+    const Program* p = (const Program*)engines[k];
+    if (!p || !p->x_in || !p->out || p->batch <= 0) return ivid_set_error("sample: program without a bound boundary", hipSuccess);
+    const long long px = (long long)p->batch * HW * 4;
+    if (p->x_bytes % px || p->out_bytes % (4 * px)) return ivid_set_error("sample: program boundary does not match the image size", hipSuccess);
+    const int cin = (int)(p->x_bytes / px), mult = (int)(p->out_bytes / (4 * px));
+    if (mult != 1 && mult != 2) return ivid_set_error("sample: program output must hold B or 2B four-channel rows", hipSuccess);
+    if (k == 0) *g = SampleGeom{p->batch, HW, cin, mult * p->batch, mult == 2};
+    else if (p->batch != g->B || cin != g->cin || (mult == 2) != g->stacked)
+      return ivid_set_error("sample: the programs of a loop must share one boundary", hipSuccess);
+  }
+  return 0;
+}
+inline long long align256(long long v) { return (v + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" long long ivid_sample_scratch_bytes(void* const* engines, int n_engines, const ivid_sample_plan* plan,
+                                               const ivid_sample_cond* cond) {
+  SampleGeom g;
+  if (!plan || plan->n_steps <= 0) { ivid_set_error("sample: empty plan", hipSuccess); return -1; }
+  if (sample_geom(engines, n_engines, plan->hw, &g) != 0) return -1;
+  const long long img = (long long)g.B * 4 * g.HW * 4;
+  return align256((long long)plan->n_steps * g.B * 8) + 2 * align256(img) + ((cond && cond->y) ? align256((long long)g.B * g.cin * g.HW * 4) : 0);
+}
+
+// DdimSampler.sample / DdpmSampler.sample (ddim.py:150-163, ddpm.py:172-185) with the frameworks' model_inference
+// (classifier_free_guidance.py:23-42, inpaint_cfg.py:51-83) as ONE call: per step [make_cond_inputs ->] UNet program (hipGraph) ->
+// fused step kernel, everything enqueued on `stream`, nothing synchronises and no host code runs between the steps.
+extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sample_plan* plan, const long long* classes,
+                           const ivid_sample_cond* cond, float* x, const float* step_noise, float* x0, void* scratch,
+                           long long scratch_bytes, void* stream) {
+  SampleGeom g;
+  if (!plan || plan->n_steps <= 0 || !plan->t_model || !plan->coef || !x) return ivid_set_error("sample: bad arguments", hipSuccess);
+  if (plan->kind != IVID_SAMPLE_DDIM && plan->kind != IVID_SAMPLE_DDPM) return ivid_set_error("sample: plan kind must be DDIM or DDPM", hipSuccess);
+  int st = sample_geom(engines, n_engines, plan->hw, &g);
+  if (st != 0) return st;
+  const bool inpaint = cond && cond->y;
+  if (inpaint && (!cond->mask || !cond->hole_noise)) return ivid_set_error("sample: inpainting needs y, mask and the hole noise", hipSuccess);
+  if (inpaint ? g.cin != (cond->mask_rgb ? 10 : 9) : g.cin != 4)
+    return ivid_set_error("sample: the programs' input channels do not match the conditioning", hipSuccess);
+  const long long need = ivid_sample_scratch_bytes(engines, n_engines, plan, cond);
+  if (!scratch || scratch_bytes < need) return ivid_set_error("sample: scratch too small (ivid_sample_scratch_bytes)", hipSuccess);
+  const ivid_ddim_coef* kd = plan->kind == IVID_SAMPLE_DDIM ? (const ivid_ddim_coef*)plan->coef : nullptr;
+  const ivid_ddpm_coef* kp = plan->kind == IVID_SAMPLE_DDPM ? (const ivid_ddpm_coef*)plan->coef : nullptr;
+  for (int i = 0; i < plan->n_steps; ++i) {   // refuse the whole loop before anything is enqueued
+    const int e = plan->engine_of_step ? plan->engine_of_step[i] : 0;
+    if (e < 0 || e >= n_engines) return ivid_set_error("sample: engine_of_step out of range", hipSuccess);
+    const bool noisy = kd ? kd[i].sigma != 0.f : kp[i].std != 0.f;
+    if (noisy && !step_noise) return ivid_set_error("sample: a step draws noise but step_noise is NULL", hipSuccess);
+    if (kd && ((kd[i].replace_rgb_w >= 0.f && !(cond && cond->rgb && cond->rgb_mask)) ||
+               (kd[i].replace_depth_w >= 0.f && !(cond && cond->depth && cond->depth_mask)) ||
+               (kd[i].constrain_w >= 0.f && !(cond && cond->convex))))
+      return ivid_set_error("sample: a step replaces / constrains but the tensors are missing", hipSuccess);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long long img_elems = (long long)g.B * 4 * g.HW;
+  char* sp = (char*)scratch;
+  long long* t_dev = (long long*)sp;  sp += align256((long long)plan->n_steps * g.B * 8);
+  float* x_alt = (float*)sp;          sp += align256(img_elems * 4);
+  float* x0_own = (float*)sp;         sp += align256(img_elems * 4);
+  float* cond_in = inpaint ? (float*)sp : nullptr;
+  float* cur = x;
+  float* nxt = x_alt;
+  float* x0w = x0 ? x0 : x0_own;
+  for (int i = 0; i < plan->n_steps; ++i) {
+    Program* p = (Program*)engines[plan->engine_of_step ? plan->engine_of_step[i] : 0];
+    long long* ti = t_dev + (long long)i * g.B;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((g.B + 255) / 256), dim3(256), 0, s, ti, plan->t_model[i], g.B);
+    const float* model_in = cur;
+    if (inpaint) {
+      const float* hn = cond->hole_noise + (long long)i * img_elems;   // per step: rgb noise [B,3,HW], then depth noise [B,1,HW]
+      st = ivid_inpaint_cond(cur, cond->y, cond->mask, cond->mask_rgb, hn, hn + (long long)g.B * 3 * g.HW, cond_in, g.B, g.HW, stream);
+      if (st != 0) return st;
+      model_in = cond_in;
+    }
+    st = ivid_unet_forward(p, model_in, ti, classes, nullptr, 1, stream);
+    if (st != 0) return st;
+    const float* eps_c = p->out;
+    const float* eps_u = g.stacked ? p->out + img_elems : nullptr;
+    const float* nz = step_noise ? step_noise + (long long)i * img_elems : nullptr;
+    if (kd) {
+      st = ivid_ddim_step(cur, eps_c, eps_u, &kd[i], cond ? cond->rgb : nullptr, cond ? cond->rgb_mask : nullptr,
+                          cond ? cond->depth : nullptr, cond ? cond->depth_mask : nullptr, cond ? cond->convex : nullptr,
+                          kd[i].sigma != 0.f ? nz : nullptr, nxt, x0w, g.B, g.HW, stream);
+    } else {
+      st = ivid_ddpm_step(cur, eps_c, eps_u, &kp[i], kp[i].std != 0.f ? nz : nullptr, nxt, x0w, g.B, g.HW, stream);
+    }
+    if (st != 0) return st;
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (cur != x) {
+    const hipError_t e = hipMemcpyAsync(x, cur, (size_t)img_elems * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return ivid_set_error("sample: result copy", e);
+  }
+  return ivid_check_launch("sample");
+}
+
 extern "C" int ivid_program_destroy(void* handle) {
   Program* p = (Program*)handle;
   if (!p) return 0;

@@ -8,7 +8,9 @@ Same constructor and `sample(num, image_size, noise, classes, steps, clip_denois
 constrain_depth, **kwargs)` signatures and the same result keys (`samples`, `pred_x_t`, `pred_x_0`).
 Extra, optional kwargs: `noise_fn(shape)->tensor` (inject the noise stream, used for seed parity
 with the CPU reference; draw order is the reference's: [cond rgb, cond depth,] step noise) and
-`keep_intermediates=False` (do not retain every step's tensors, ddim.py:161-162).
+`keep_intermediates=False` (do not retain every step's tensors, ddim.py:161-162), and
+`device_loop=True`: the whole loop as ONE C call (`ivid_sample`, samplers/device_loop.py) — no host
+code between the steps, bit-identical samples; returns `pred_x_t = []`, `pred_x_0 = [the last step's]`.
 """
 import ctypes as C
 
@@ -108,6 +110,16 @@ class DdimSampler:
         steps = steps if steps is not None else self.framework.timesteps
         jump = self.framework.timesteps // steps
         pairs = [(jump * (i + 1), jump * i) for i in reversed(range(steps))]
+        if kwargs.pop("device_loop", False):   # the whole loop as ONE C call (ivid_sample): device_loop.py
+            from . import device_loop
+
+            def step(t, t_prev):
+                probe = self._coef(t, t_prev, eta, 0.0, clip_denoised, -1.0, -1.0, -1.0)
+                return (t - 1, lambda s, wr, wd, wc: self._coef(t, t_prev, eta, s, clip_denoised, wr, wd, wc),
+                        float(probe.sigma) != 0.0 and t_prev != 0)
+            ret = device_loop.run(self, _lib.SAMPLE_DDIM, img, [step(t, tp) for t, tp in pairs], classes, kwargs)
+            backbone.train()
+            return ret
         ret = AttrDict({"samples": None, "pred_x_t": [], "pred_x_0": []})
         it = tqdm(pairs, desc="DDIM Sampling", disable=not verbose) if tqdm is not None else pairs
         for t, t_prev in it:

@@ -85,6 +85,12 @@ class DdpmSampler:
         img = noise if noise is not None else noise_fn(shape)
         img = img.to(device)
         indices = list(range(self.framework.timesteps))[::-1]
+        if kwargs.pop("device_loop", False):   # the whole loop as ONE C call (ivid_sample): device_loop.py
+            from . import device_loop
+            ret = device_loop.run(self, _lib.SAMPLE_DDPM, img,
+                                  [(i, (lambda s, *_, i=i: self._coef(i, s, clip_denoised)), i != 0) for i in indices], classes, kwargs)
+            backbone.train()
+            return ret
         ret = AttrDict({"samples": None, "pred_x_t": [], "pred_x_0": []})
         it = tqdm(indices, desc="DDPM Sampling", disable=not verbose) if tqdm is not None else indices
         for i in it:

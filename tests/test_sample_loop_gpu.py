@@ -1,0 +1,147 @@
+"""`ivid_sample` (include/ivid_hip.h): the whole DDIM / DDPM sampling loop as ONE C call over UNet programs (SURVEY.md §8(b);
+reference loops: diffusion/samplers/ddim.py:150-163, ddpm.py:172-185).  The bar is BIT-identity with the host-driven loop of the
+same package on the same noise stream (same programs, same kernels, same order) -- which the other tests hold against the live
+reference's chains -- plus the reference chain goldens directly, and refusal of malformed plans before anything is enqueued."""
+import ctypes as C_
+
+import pytest
+import torch
+
+import common as C
+import gpu_util as G
+from test_unet_gpu import build
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_noise_fn():
+    return lambda shape: torch.randn(shape).cuda()   # torch's CPU generator = the reference's stream
+
+
+def _both(make, seed, **kw):
+    """The same chain driven from the host and as one C call, each on a fresh model and the same CPU noise stream."""
+    out = []
+    for dev in (False, True):
+        smp, args = make()
+        torch.manual_seed(seed)
+        out.append(smp.sample(*args, verbose=False, noise_fn=_cpu_noise_fn(), keep_intermediates=True, device_loop=dev, **kw))
+    return out
+
+
+def test_ddim_cfg_chain_device_loop_is_bit_identical_and_matches_the_reference_golden():
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("mini_ddim_cfg")
+
+    def make():
+        m, _ = build(C.MINI, 0, "fp32")
+        fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+        return samplers.DdimSampler(fw), (2,)
+    host, dev = _both(make, 5, noise=torch.from_numpy(g["x_T"]).cuda(), classes=torch.from_numpy(g["classes"]).cuda(), steps=5,
+                      strength=0.5, eta=0.5)
+    assert torch.equal(host.samples, dev.samples)
+    assert torch.equal(host.pred_x_0[-1], dev.pred_x_0[-1]) and dev.pred_x_t == []
+    e = C.rel_l2(dev.samples.cpu(), g["samples"])
+    G.report("device_loop/mini_ddim_cfg", samples=e)
+    assert e < 1e-3
+
+
+def test_ddim_inpaint_chain_with_replacement_and_depth_constraint_device_loop_is_bit_identical():
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("mini_ddim_inpaint")
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    y, mask, mask_rgb, convex = T("y"), T("mask"), T("mask_rgb"), T("convex")
+
+    def make():
+        m, _ = build(C.MINI_COND, 2, "fp32")
+        fw = frameworks.InpaintCFG(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
+        return samplers.DdimSampler(fw), (2,)
+    host, dev = _both(make, 7, noise=T("x_T"), classes=T("classes"), steps=4, strength=3.0, y=y, mask=mask, mask_rgb=mask_rgb,
+                      replace_rgb=(0.1, y[:, :3], mask_rgb), replace_depth=(0.2, y[:, 3:], mask), constrain_depth=(0.5, convex))
+    assert torch.equal(host.samples, dev.samples)
+    assert torch.equal(host.pred_x_0[-1], dev.pred_x_0[-1])
+    e = C.rel_l2(dev.samples.cpu(), g["samples"])
+    G.report("device_loop/mini_ddim_inpaint", samples=e)
+    assert e < 1e-3
+
+
+def test_ddpm_chain_device_loop_in_several_calls_is_bit_identical():
+    """100 ancestral steps of an unconditional model (plain programs, classes = NULL), the loop cut into calls of 64 + 36 steps."""
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("mini_ddpm")
+
+    def make():
+        m, _ = build(C.MINI_UNCLASS, 1, "fp32")
+        fw = frameworks.GaussianDiffusion(m, timesteps=100, beta_schedule="linear")
+        return samplers.DdpmSampler(fw), (2,)
+    host, dev = _both(make, 9, noise=torch.from_numpy(g["x_T"]).cuda())
+    assert torch.equal(host.samples, dev.samples)
+    assert C.rel_l2(dev.samples.cpu(), g["samples"]) < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["fp16sx", "fp16sa3"])
+def test_device_loop_walks_the_precision_ladder_like_the_host_loop(precision):
+    """A ladder mode: every step must run the program of the tier its timestep AND the guidance strength select (strength 3: the
+    first, pure-noise step in the guidance-aware bf16x3 tier), i.e. the chain is bit-identical to the host loop, which announces
+    both per step."""
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("mini_ddim_cfg")
+
+    def make():
+        m, _ = build(C.MINI, 0, precision)
+        fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+        return samplers.DdimSampler(fw), (2,)
+    host, dev = _both(make, 5, noise=torch.from_numpy(g["x_T"]).cuda(), classes=torch.from_numpy(g["classes"]).cuda(), steps=10,
+                      strength=3.0, eta=0.0)
+    assert torch.equal(host.samples, dev.samples)
+    smp, _ = make()
+    bb = smp.framework.backbone
+    tiers = {bb.tier_of(t - 1, 3.0) for t in range(100, 1001, 100)}
+    assert len(tiers) >= 3, tiers      # the 10-step schedule really visits several programs
+
+
+def test_device_loop_refuses_what_it_does_not_cover():
+    from ivid_amd.diffusion import frameworks, samplers
+    m, _ = build(C.MINI, 0, "fp32")
+    fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    smp = samplers.DdimSampler(fw)
+    cls = torch.tensor([1, 2]).cuda()
+    with pytest.raises(NotImplementedError):
+        smp.sample(2, classes=cls, steps=2, strength=0.0, verbose=False, device_loop=True)       # scaled single branch: host loop
+    with pytest.raises(NotImplementedError):
+        smp.sample(2, classes=cls, steps=2, verbose=False, device_loop=True, some_framework_kwarg=1)
+
+
+def test_ivid_sample_validates_the_plan_before_enqueueing_anything():
+    from ivid_amd import _lib
+    m, _ = build(C.MINI, 0, "fp32")
+    lib = _lib.load()
+    plan_obj = m.plan(2, True)
+    S = C.MINI["image_size"]
+    h = (C_.c_void_p * 1)(plan_obj.program.value)
+    x = torch.zeros(2, 4, S, S, device="cuda")
+    before = x.clone()
+    stream = torch.cuda.Stream()             # the programs capture their hipGraph on it: not the legacy default stream
+    torch.cuda.synchronize()
+
+    def call(n_steps=2, eng=(0, 0), hw=S * S, sigma=0.0, noise=None, scratch_bytes=None, w_rgb=-1.0):
+        coefs = (_lib.DdimCoef * n_steps)()
+        for k in coefs:
+            k.sqrt_recip_ac, k.sqrt_recipm1_ac, k.sqrt_ac_prev, k.dir_coef, k.nonzero = 1.1, 0.5, 0.9, 0.4, 1.0
+            k.sigma, k.replace_rgb_w, k.replace_depth_w, k.constrain_w = sigma, w_rgb, -1.0, -1.0
+        tm = (C_.c_longlong * n_steps)(*([5] * n_steps))
+        e = (C_.c_int * n_steps)(*eng)
+        plan = _lib.SamplePlan(_lib.SAMPLE_DDIM, n_steps, hw, tm, C_.cast(coefs, C_.c_void_p), e)
+        need = lib.ivid_sample_scratch_bytes(h, 1, C_.byref(plan), None)
+        sc = torch.empty(max(int(need), 256) if scratch_bytes is None else scratch_bytes, dtype=torch.uint8, device="cuda")
+        return lib.ivid_sample(h, 1, C_.byref(plan), None, None, x.data_ptr(), noise, None, sc.data_ptr(), sc.numel(),
+                               stream.cuda_stream), need
+    assert call(eng=(0, 1))[0] != 0 and b"engine_of_step" in lib.ivid_last_error()
+    assert call(hw=S * S + 1)[0] != 0 and b"image size" in lib.ivid_last_error()
+    assert call(sigma=0.5)[0] != 0 and b"step_noise" in lib.ivid_last_error()
+    assert call(w_rgb=0.1)[0] != 0 and b"missing" in lib.ivid_last_error()
+    assert call(scratch_bytes=256)[0] != 0 and b"scratch" in lib.ivid_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(x, before)            # nothing ran
+    st, need = call()
+    torch.cuda.synchronize()
+    assert st == 0 and need > 0 and torch.isfinite(x).all()
