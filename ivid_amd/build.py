@@ -64,30 +64,33 @@ def build_all(verbose=True, force=False):
 
 HOST_SRC = os.path.join(os.path.dirname(HERE), "examples", "unet_engine_host.c")
 HOST_BIN = os.path.join(LIBDIR, "unet_engine_host")
+LOOP_SRC = os.path.join(os.path.dirname(HERE), "examples", "sample_loop_host.c")
+LOOP_BIN = os.path.join(LIBDIR, "sample_loop_host")
 
 
 def _build_host_example(verbose):
-    """examples/unet_engine_host.c: a C host that runs a planned forward from an engine file through the C ABI alone (plain C
-    compiler, linked against libivid_hip.so and the HIP runtime)."""
-    if not os.path.exists(HOST_SRC):
-        return
-    if os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) > max(os.path.getmtime(HOST_SRC), os.path.getmtime(LIB)):
-        return
-    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = ["gcc", "-O2", "-std=c11", "-I" + os.path.join(rocm, "include"), HOST_SRC, "-o", HOST_BIN, "-L" + LIBDIR, "-livid_hip",
-           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        err = None if r.returncode == 0 else f"{r.stdout}\n{r.stderr}"
-    except OSError as e:                      # no gcc on this machine
-        err = str(e)
-    if err is not None:
-        # an optional example must not turn a library that linked into a failed build: say so and carry on (the test that runs
-        # the C host, tests/test_engine_gpu.py, reports the missing binary itself)
-        import warnings
-        warnings.warn(f"examples/unet_engine_host.c was not built (the library itself is fine):\n{err}")
+    """examples/unet_engine_host.c, examples/sample_loop_host.c: C hosts that run a planned forward / a whole sampling loop from
+    engine files through the C ABI alone (plain C compiler, linked against libivid_hip.so and the HIP runtime)."""
+    for src, binary in ((HOST_SRC, HOST_BIN), (LOOP_SRC, LOOP_BIN)):
+        if not os.path.exists(src):
+            continue
+        if os.path.exists(binary) and os.path.getmtime(binary) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+            continue
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cmd = ["gcc", "-O2", "-std=c11", "-I" + os.path.join(rocm, "include"), src, "-o", binary, "-L" + LIBDIR, "-livid_hip",
+               "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            err = None if r.returncode == 0 else f"{r.stdout}\n{r.stderr}"
+        except OSError as e:                      # no gcc on this machine
+            err = str(e)
+        if err is not None:
+            # an optional example must not turn a library that linked into a failed build: say so and carry on (the tests that run
+            # the C hosts, tests/test_engine_gpu.py and tests/test_sample_loop_gpu.py, report a missing binary themselves)
+            import warnings
+            warnings.warn(f"{os.path.relpath(src, os.path.dirname(HERE))} was not built (the library itself is fine):\n{err}")
 
 
 if __name__ == "__main__":

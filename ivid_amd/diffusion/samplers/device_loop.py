@@ -136,3 +136,25 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
     for p in plans[1:]:
         p.stream.wait_stream(ls)
     return AttrDict({"samples": x, "pred_x_t": [], "pred_x_0": [x0]})
+
+
+def write_plan_file(path, kind, hw, batch, t_model, engine_of_step, coefs, classes=None, step_noise=None, n_engines=None):
+    """The host tables of one `ivid_sample` call as a file a C host reads (examples/sample_loop_host.c documents the layout):
+    `coefs` = the samplers' `_coef(...)` structs in sampling order, `classes` an int64 tensor / sequence or None, `step_noise` a
+    float32 tensor [n_steps, batch, 4, H, W] or None."""
+    import struct
+
+    import numpy as np
+    n = len(t_model)
+    assert len(engine_of_step) == n and len(coefs) == n
+    ne = n_engines if n_engines is not None else max(engine_of_step) + 1
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i", 0x50535649, kind, n, hw, batch, int(classes is not None), int(step_noise is not None), ne))
+        f.write(np.asarray([int(t) for t in t_model], dtype="<i8").tobytes())
+        f.write(np.asarray([int(e) for e in engine_of_step], dtype="<i4").tobytes())
+        for k in coefs:
+            f.write(bytes(k))
+        if classes is not None:
+            f.write(np.asarray(classes.cpu() if hasattr(classes, "cpu") else classes, dtype="<i8").tobytes())
+        if step_noise is not None:
+            f.write(np.ascontiguousarray(step_noise.float().cpu().numpy(), dtype="<f4").tobytes())

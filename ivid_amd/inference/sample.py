@@ -58,6 +58,8 @@ def sample_all(framework_uncond, framework_cond, seeds_or_num_samples, steps_unc
                 [torch.randn((1,) + tuple(shape[1:]), device=device, generator=gj) for gj in g], dim=0)}
         else:
             extra = {}
+        if os.environ.get("IVID_DEVICE_LOOP", "0") == "1":   # every chain as ONE C call (ivid_sample); bit-identical samples
+            extra["device_loop"] = True
         if sampler_cond is not None:
             key = (bs, len(s_modelviews))
             if key not in renderers:

@@ -3,7 +3,10 @@ reference loops: diffusion/samplers/ddim.py:150-163, ddpm.py:172-185).  The bar 
 same package on the same noise stream (same programs, same kernels, same order) -- which the other tests hold against the live
 reference's chains -- plus the reference chain goldens directly, and refusal of malformed plans before anything is enqueued."""
 import ctypes as C_
+import os
+import subprocess
 
+import numpy as np
 import pytest
 import torch
 
@@ -145,3 +148,70 @@ def test_ivid_sample_validates_the_plan_before_enqueueing_anything():
     st, need = call()
     torch.cuda.synchronize()
     assert st == 0 and need > 0 and torch.isfinite(x).all()
+
+
+def test_c_host_samples_a_guided_ddim_chain_from_engine_files_without_python(tmp_path):
+    """examples/sample_loop_host.c: engine files of every precision tier the schedule visits + the plan tables -> ONE ivid_sample
+    call from a C program.  Must equal the Python-driven chain of the same model bit for bit."""
+    from ivid_amd import _lib
+    from ivid_amd import build as B
+    from ivid_amd.diffusion import frameworks, samplers
+    from ivid_amd.diffusion.samplers import device_loop
+    from ivid_amd.diffusion.samplers.utils import equivalent_timestep
+    if not os.path.exists(B.LOOP_BIN):
+        raise RuntimeError(f"{B.LOOP_BIN} missing: python -m ivid_amd.build")
+    args, bs, steps, strength = C.MINI128, 2, 10, 3.0
+    m, _ = build(args, 0, "fp16sx")
+    fw = frameworks.ClassifierFreeGuidance(m, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+    smp = samplers.DdimSampler(fw)
+    S = args["image_size"]
+    xT = C.seeded_randn(21, bs, 4, S, S).cuda()
+    cls = torch.tensor([3, 7]).cuda()
+    want = smp.sample(bs, noise=xT, classes=cls, steps=steps, strength=strength, eta=0.0, verbose=False).samples.cpu().numpy()
+    jump = 1000 // steps
+    pairs = [(jump * (i + 1), jump * i) for i in reversed(range(steps))]
+    tiers = [m.tier_of(equivalent_timestep(fw, t - 1), strength) for t, _ in pairs]
+    order = sorted(set(tiers))
+    assert len(order) == 3
+    engines = []
+    for k in order:
+        engines.append(str(tmp_path / f"tier{k}.eng"))
+        m.export_engine(bs, True, path=engines[-1], high_t=k)
+    device_loop.write_plan_file(str(tmp_path / "plan.bin"), _lib.SAMPLE_DDIM, S * S, bs, [t - 1 for t, _ in pairs],
+                                [order.index(k) for k in tiers],
+                                [smp._coef(t, tp, 0.0, strength, False, -1.0, -1.0, -1.0) for t, tp in pairs], classes=cls)
+    xT.cpu().numpy().tofile(tmp_path / "xT.bin")
+    del m, fw, smp
+    torch.cuda.synchronize()
+    r = subprocess.run([B.LOOP_BIN, str(tmp_path / "plan.bin"), str(tmp_path / "xT.bin"), str(tmp_path / "out.bin")] + engines,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "one call" in r.stdout
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(want.shape)
+    assert np.array_equal(got, want)
+    # an engine count that does not match the plan is refused by the host
+    r = subprocess.run([B.LOOP_BIN, str(tmp_path / "plan.bin"), str(tmp_path / "xT.bin"), str(tmp_path / "o2.bin")] + engines[:2],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "engine" in r.stderr
+
+
+def test_sample_all_with_the_device_loop_is_bit_identical_to_the_host_loop(monkeypatch):
+    """The sampling driver end to end (inference/sample.py:75-139: unconditional DDIM + CFG -> mesh -> warp -> InpaintCFG with the
+    reference's conditioning wiring, three views) with every chain as ONE ivid_sample call (IVID_DEVICE_LOOP=1): the same views and
+    conditioning tensors as the host-driven loops, bit for bit, on per-seed device noise."""
+    from ivid_amd.diffusion import frameworks
+    from ivid_amd.diffusion.backbones import AdmUnet2d
+    from ivid_amd.inference.sample import sample_all
+    from ivid_amd.rgbd_3d import camera
+    views = camera.viewset("3x9")[:3]
+    outs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("IVID_DEVICE_LOOP", env)
+        mu = AdmUnet2d(**C.MINI, precision="fp16sx"); mu.load_state_dict(C.synth_weights(C.MINI, 0)); mu = mu.cuda()
+        mc = AdmUnet2d(**C.MINI_COND, precision="fp16sx"); mc.load_state_dict(C.synth_weights(C.MINI_COND, 2)); mc = mc.cuda()
+        fu = frameworks.ClassifierFreeGuidance(mu, timesteps=1000, beta_schedule="linear", p_uncond=0.1)
+        fc = frameworks.InpaintCFG(mc, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
+        outs.append(list(sample_all(fu, fc, [0, 1, 2], 6, 4, views, classes=[3, 4, 5], guidance=3.0, batchsize=3, erode_rgb=1)))
+    for (sa, ca), (sb, cb) in zip(*outs):
+        assert torch.equal(sa, sb)
+        assert all(torch.equal(ca[k], cb[k]) for k in ca)
