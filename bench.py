@@ -994,6 +994,8 @@ def bench_c3(a, rank, world, dev, C, parallel, dist):
                                   ", + rgbd_imagenet_adm_256_128_small_sr (SuperResCFG 3.0, DDIM 50) on all %d views" % nviews if fsr is not None else ""),
                    "parallelism": "sample-parallel x%d" % world},
         "seconds_per_batch": round(dt, 3),
+        "sampling_loop": ("one C call per chain (ivid_sample, IVID_DEVICE_LOOP=1): no host code between the steps"
+                          if os.environ.get("IVID_DEVICE_LOOP", "0") == "1" else "host-driven (Python issues every step)"),
         "per_rank_seconds": per_rank_seconds, "ranks_seen": a.ranks_seen,
         "unet_forward_ms": {"uncond_stacked_bs%d" % (2 * bs): {"tier %d (%s)" % (k, mu._tier_modes[k]): {"ms": round(v, 3), "model_calls": cu[k]} for k, v in sorted(mu_ms.items())},
                             "cond_stacked_bs%d" % (2 * bs): {"tier %d (%s)" % (k, mc._tier_modes[k]): {"ms": round(v, 3), "model_calls_per_view": cc[k]} for k, v in sorted(mc_ms.items())},

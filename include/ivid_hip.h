@@ -377,7 +377,9 @@ int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int 
  *                    y [B,4,HW], mask [B,1,HW], mask_rgb [B,1,HW] or NULL, hole_noise [n_steps][B,4,HW] (per step the rgb
  *                    noise [B,3,HW] followed by the depth noise [B,1,HW], inpaint_cfg.py:36-45) -- y == NULL: the model is fed x_t;
  *                    rgb [B,3,HW], rgb_mask, depth, depth_mask, convex [B,1,HW]: replace_rgb / replace_depth / constrain_depth of
- *                    DdimSampler.sample_once (ddim.py:86-95), needed when a step's weight is >= 0
+ *                    DdimSampler.sample_once (ddim.py:86-95), needed when a step's weight is >= 0;
+ *                    sr_y [B,sr_channels,sr_size,sr_size]: SuperResCFG.make_cond_inputs per step (sr_cfg.py:23-36: the model is fed
+ *                    cat[x_t, bilinear upsample of sr_y]); not together with y
  *   x              : device fp32 [B,4,HW]: x_T on entry, the sample on return (when the stream has drained)
  *   step_noise     : device fp32 [n_steps][B,4,HW] or NULL when no step draws noise (DDIM with eta = 0)
  *   x0             : NULL or device fp32 [B,4,HW]: pred_x_0 of the last step
@@ -400,6 +402,7 @@ typedef struct {
 typedef struct {
   const float* y; const float* mask; const float* mask_rgb; const float* hole_noise;
   const float* rgb; const float* rgb_mask; const float* depth; const float* depth_mask; const float* convex;
+  const float* sr_y; int sr_channels; int sr_size;
 } ivid_sample_cond;
 long long ivid_sample_scratch_bytes(void* const* engines, int n_engines, const ivid_sample_plan* plan, const ivid_sample_cond* cond);
 int ivid_sample(void* const* engines, int n_engines, const ivid_sample_plan* plan, const long long* classes,

@@ -80,7 +80,8 @@ class SamplePlan(C.Structure):      # ivid_sample_plan
 
 
 class SampleCond(C.Structure):      # ivid_sample_cond
-    _fields_ = [(n, C.c_void_p) for n in ("y", "mask", "mask_rgb", "hole_noise", "rgb", "rgb_mask", "depth", "depth_mask", "convex")]
+    _fields_ = ([(n, C.c_void_p) for n in ("y", "mask", "mask_rgb", "hole_noise", "rgb", "rgb_mask", "depth", "depth_mask", "convex",
+                                            "sr_y")] + [("sr_channels", C.c_int), ("sr_size", C.c_int)])
 
 
 SAMPLE_DDIM, SAMPLE_DDPM = 0, 1

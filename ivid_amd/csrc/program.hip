@@ -355,7 +355,8 @@ extern "C" long long ivid_sample_scratch_bytes(void* const* engines, int n_engin
   if (!plan || plan->n_steps <= 0) { ivid_set_error("sample: empty plan", hipSuccess); return -1; }
   if (sample_geom(engines, n_engines, plan->hw, &g) != 0) return -1;
   const long long img = (long long)g.B * 4 * g.HW * 4;
-  return align256((long long)plan->n_steps * g.B * 8) + 2 * align256(img) + ((cond && cond->y) ? align256((long long)g.B * g.cin * g.HW * 4) : 0);
+  return align256((long long)plan->n_steps * g.B * 8) + 2 * align256(img) +
+         ((cond && (cond->y || cond->sr_y)) ? align256((long long)g.B * g.cin * g.HW * 4) : 0);
 }
 
 // DdimSampler.sample / DdpmSampler.sample (ddim.py:150-163, ddpm.py:172-185) with the frameworks' model_inference
@@ -370,8 +371,16 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
   int st = sample_geom(engines, n_engines, plan->hw, &g);
   if (st != 0) return st;
   const bool inpaint = cond && cond->y;
+  const bool superres = cond && cond->sr_y;
+  if (inpaint && superres) return ivid_set_error("sample: y and sr_y are two different frameworks' conditioning", hipSuccess);
   if (inpaint && (!cond->mask || !cond->hole_noise)) return ivid_set_error("sample: inpainting needs y, mask and the hole noise", hipSuccess);
-  if (inpaint ? g.cin != (cond->mask_rgb ? 10 : 9) : g.cin != 4)
+  int S = 0;
+  if (superres) {
+    while ((long long)S * S < g.HW) ++S;
+    if (S * S != g.HW || cond->sr_channels <= 0 || cond->sr_size <= 0 || cond->sr_size > S)
+      return ivid_set_error("sample: super-resolution needs a square image and sr_channels / sr_size", hipSuccess);
+  }
+  if (g.cin != (inpaint ? (cond->mask_rgb ? 10 : 9) : superres ? 4 + cond->sr_channels : 4))
     return ivid_set_error("sample: the programs' input channels do not match the conditioning", hipSuccess);
   const long long need = ivid_sample_scratch_bytes(engines, n_engines, plan, cond);
   if (!scratch || scratch_bytes < need) return ivid_set_error("sample: scratch too small (ivid_sample_scratch_bytes)", hipSuccess);
@@ -393,7 +402,7 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
   long long* t_dev = (long long*)sp;  sp += align256((long long)plan->n_steps * g.B * 8);
   float* x_alt = (float*)sp;          sp += align256(img_elems * 4);
   float* x0_own = (float*)sp;         sp += align256(img_elems * 4);
-  float* cond_in = inpaint ? (float*)sp : nullptr;
+  float* cond_in = (inpaint || superres) ? (float*)sp : nullptr;
   float* cur = x;
   float* nxt = x_alt;
   float* x0w = x0 ? x0 : x0_own;
@@ -405,6 +414,10 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
     if (inpaint) {
       const float* hn = cond->hole_noise + (long long)i * img_elems;   // per step: rgb noise [B,3,HW], then depth noise [B,1,HW]
       st = ivid_inpaint_cond(cur, cond->y, cond->mask, cond->mask_rgb, hn, hn + (long long)g.B * 3 * g.HW, cond_in, g.B, g.HW, stream);
+      if (st != 0) return st;
+      model_in = cond_in;
+    } else if (superres) {
+      st = ivid_sr_cond(cur, cond->sr_y, cond_in, g.B, 4, cond->sr_channels, S, cond->sr_size, stream);
       if (st != 0) return st;
       model_in = cond_in;
     }

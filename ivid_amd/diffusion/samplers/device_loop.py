@@ -4,8 +4,8 @@ model input, run the UNet program of the step's precision tier, apply the fused 
 no host code between the steps.  Opt-in through the samplers' `device_loop=True`; results are bit-identical to the host-driven loop
 (same programs, same kernels, same order, same noise draws: tests/test_sample_loop_gpu.py).
 
-What it covers is what the sampling driver issues (inference/sample.py:75-139): GaussianDiffusion / ClassifierFreeGuidance on x_t
-itself and InpaintCFG with `replace_rgb` / `replace_depth` / `constrain_depth`; anything else (a foreign framework or backbone, a
+What it covers is what the sampling drivers issue (inference/sample.py:75-139): GaussianDiffusion / ClassifierFreeGuidance on x_t
+itself, InpaintCFG with `replace_rgb` / `replace_depth` / `constrain_depth`, SuperResCFG on a low-resolution `y`; anything else (a foreign framework or backbone, a
 guidance strength <= 0 with classes, further framework arguments) raises NotImplementedError — the caller keeps the host loop
 for those.  Intermediates are not kept: `pred_x_t` comes back empty and `pred_x_0` holds the last step's prediction.
 """
@@ -29,15 +29,15 @@ def _backbone_of(framework):
 def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
     """steps: list of (t_model, coef_factory(strength, w_rgb, w_depth, w_con) -> ctypes coefficient struct, draws_noise) in sampling
     order.  Returns AttrDict(samples, pred_x_t=[], pred_x_0=[last pred_x_0])."""
-    from ..frameworks import ClassifierFreeGuidance, GaussianDiffusion, InpaintCFG
+    from ..frameworks import ClassifierFreeGuidance, GaussianDiffusion, InpaintCFG, SuperResCFG
     fw = sampler.framework
     bb = _backbone_of(fw)
     kwargs = dict(kwargs)
     injected = kwargs.pop("noise_fn", None)
     noise_fn = injected or (lambda shape: default_noise(shape, img.device))
-    strength = kwargs.pop("strength", 3.0 if type(fw) in (ClassifierFreeGuidance, InpaintCFG) else 0.0)
+    strength = kwargs.pop("strength", 3.0 if type(fw) in (ClassifierFreeGuidance, InpaintCFG, SuperResCFG) else 0.0)
     inpaint = type(fw) is InpaintCFG
-    if type(fw) not in (GaussianDiffusion, ClassifierFreeGuidance, InpaintCFG):
+    if type(fw) not in (GaussianDiffusion, ClassifierFreeGuidance, InpaintCFG, SuperResCFG):
         raise NotImplementedError(f"device_loop: framework {type(fw).__name__} is driven from the host")
     x = as_f32(img).clone()
     b, c, h, w = x.shape
@@ -65,6 +65,11 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
         cond.y, cond.mask = dev(kwargs.pop("y"), 4), dev(kwargs.pop("mask"), 1)
         mr = kwargs.pop("mask_rgb", None)
         cond.mask_rgb = dev(mr, 1) if mr is not None else None
+    if type(fw) is SuperResCFG:
+        y = as_f32(kwargs.pop("y").to(x.device))
+        y = as_f32(y.expand(b, -1, -1, -1))
+        keepalive.append(y)
+        cond.sr_y, cond.sr_channels, cond.sr_size = y.data_ptr(), y.shape[1], y.shape[-1]
     if kind == _lib.SAMPLE_DDIM:
         rr, rd, cd = kwargs.pop("replace_rgb", None), kwargs.pop("replace_depth", None), kwargs.pop("constrain_depth", None)
         if rr is not None:                   # `is not None` / truthiness exactly as DdimSampler.sample_once (ddim.py:86-95)
@@ -123,7 +128,7 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
         if inpaint:
             cond.hole_noise = hole.data_ptr()
         plan = _lib.SamplePlan(kind, n, hw, tm, C.cast(coefs, C.c_void_p), eng)
-        use_cond = C.byref(cond) if (inpaint or w_rgb >= 0 or w_dep >= 0) else None
+        use_cond = C.byref(cond) if (inpaint or cond.sr_y or w_rgb >= 0 or w_dep >= 0) else None
         need = _lib.load().ivid_sample_scratch_bytes(handles, len(plans), C.byref(plan), use_cond)
         if need < 0:
             _lib.check(-1, "ivid_sample_scratch_bytes")

@@ -4,6 +4,8 @@ The reference ships the SR model (`rgbd_imagenet_adm_256_128_small_sr.json`, `Su
 driver for it; its only sampling call is the trainer's preview (`SuperResTrainer.sample`, trainers/superres.py:120-124:
 `sampler.sample(batch, y=..., classes=..., steps=50, strength=3.0)`).  This is that call as a function over the views
 produced by `sample_all`, so the chain  uncond -> warp/inpaint views -> SR  runs on the GPU end to end."""
+import os
+
 import torch
 
 from ..diffusion import samplers
@@ -17,6 +19,8 @@ def super_resolve(framework_sr, views, classes=None, steps=50, strength=3.0, bat
     dev = views.device
     out = []
     extra = {"noise_fn": noise_fn} if noise_fn is not None else {}
+    if os.environ.get("IVID_DEVICE_LOOP", "0") == "1":   # every chain as ONE C call (ivid_sample); bit-identical samples
+        extra["device_loop"] = True
     for i in range(0, views.shape[0], batchsize):
         y = views[i:i + batchsize].float().contiguous()
         b = y.shape[0]
