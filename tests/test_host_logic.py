@@ -550,3 +550,35 @@ def test_bench_unet_share_walks_the_real_schedules_and_refuses_an_inconsistent_s
     assert bench.share_outside(10.2, 0.0, 10.0) < 0                        # timing noise of a loop that is all forwards: reported as is
     with pytest.raises(ValueError):
         bench.share_outside(56.3, 0.0, 51.9)                               # round 5's figures: refused, not clamped to 0
+
+
+def test_sample_plan_file_layout_matches_what_the_c_host_parses(tmp_path):
+    """samplers/device_loop.write_plan_file -> examples/sample_loop_host.c: header of eight int32, then the tables in the order and
+    sizes the C host computes its expected file size from (ctypes mirrors of ivid_ddim_coef / ivid_ddpm_coef have the C sizes)."""
+    import ctypes
+    import struct
+
+    import numpy as np
+    import torch
+    from ivid_amd import _lib
+    from ivid_amd.diffusion.samplers import device_loop
+    assert ctypes.sizeof(_lib.DdimCoef) == 44 and ctypes.sizeof(_lib.DdpmCoef) == 28
+    n, b, hw = 3, 2, 16
+    coefs = []
+    for i in range(n):
+        k = _lib.DdimCoef()
+        k.sigma, k.cfg_strength, k.clip_denoised = 0.25 * i, 3.0, 1
+        coefs.append(k)
+    noise = torch.arange(n * b * 4 * hw, dtype=torch.float32).reshape(n, b, 4, 4, 4)
+    path = tmp_path / "plan.bin"
+    device_loop.write_plan_file(str(path), _lib.SAMPLE_DDIM, hw, b, [899, 499, 99], [0, 1, 2], coefs, classes=torch.tensor([5, 7]), step_noise=noise)
+    blob = path.read_bytes()
+    assert struct.unpack("<8i", blob[:32]) == (0x50535649, 0, n, hw, b, 1, 1, 3)
+    assert len(blob) == 32 + 8 * n + 4 * n + 44 * n + 8 * b + 4 * n * b * 4 * hw
+    off = 32
+    assert list(np.frombuffer(blob, "<i8", n, off)) == [899, 499, 99]; off += 8 * n
+    assert list(np.frombuffer(blob, "<i4", n, off)) == [0, 1, 2]; off += 4 * n
+    k1 = _lib.DdimCoef.from_buffer_copy(blob[off + 44:off + 88])
+    assert (k1.sigma, k1.cfg_strength, k1.clip_denoised) == (0.25, 3.0, 1); off += 44 * n
+    assert list(np.frombuffer(blob, "<i8", b, off)) == [5, 7]; off += 8 * b
+    assert np.array_equal(np.frombuffer(blob, "<f4", -1, off), noise.numpy().ravel())
