@@ -360,6 +360,12 @@ int ivid_inpaint_cond(const float* x, const float* y, const float* mask, const f
  * y[B,Cy,s,s] with align_corners=False] (fp32 NCHW), torch's upsample_bilinear2d arithmetic. */
 int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int Cy, int S, int s, void* stream);
 
+/* ---- counter-based Gaussian noise on the device (what `torch.randn` / `randn_like` are to the reference's samplers, ddim.py:101,
+ * ddpm.py:128, inpaint_cfg.py:36-45): out[i] ~ N(0,1), a pure function of (seed, stream_id, i) -- Philox4x32-10 blocks of four
+ * values, 24-bit uniforms, Box-Muller -- so that a chain's noise needs no buffers and does not depend on launch shapes, ranks
+ * or call order.  out: device fp32, 16-byte aligned. */
+int ivid_randn(unsigned long long seed, unsigned long long stream_id, float* out, long long n, void* stream);
+
 /* ---- the whole sampling loop as ONE call (SURVEY.md 8(b) `ivid_sample(handle, plan*, ...)`) ----
  * DdimSampler.sample / DdpmSampler.sample (diffusion/samplers/ddim.py:150-163, ddpm.py:172-185) with the frameworks'
  * model_inference inside (classifier_free_guidance.py:23-42; inpaint_cfg.py:24-49,51-83): per step [make_cond_inputs ->] one
@@ -381,7 +387,7 @@ int ivid_sr_cond(const float* x, const float* y, float* out, int B, int Cx, int 
  *                    sr_y [B,sr_channels,sr_size,sr_size]: SuperResCFG.make_cond_inputs per step (sr_cfg.py:23-36: the model is fed
  *                    cat[x_t, bilinear upsample of sr_y]); not together with y
  *   x              : device fp32 [B,4,HW]: x_T on entry, the sample on return (when the stream has drained)
- *   step_noise     : device fp32 [n_steps][B,4,HW] or NULL when no step draws noise (DDIM with eta = 0)
+ *   step_noise     : device fp32 [n_steps][B,4,HW]; NULL when no step draws noise (DDIM with eta = 0) or with plan->generate_noise
  *   x0             : NULL or device fp32 [B,4,HW]: pred_x_0 of the last step
  *   scratch        : device memory of ivid_sample_scratch_bytes(...) bytes, owned by the caller, free for reuse when the
  *                    stream has drained
@@ -398,6 +404,9 @@ typedef struct {
   const long long* t_model;  /* host [n_steps] */
   const void* coef;          /* host [n_steps] */
   const int* engine_of_step; /* host [n_steps] or NULL (= engines[0] for every step) */
+  int generate_noise;        /* != 0: noise the caller did not pass (step_noise / cond->hole_noise NULL) is drawn on the device:    */
+  int first_step;            /*       ivid_randn(noise_seed, stream_id = 2 * (first_step + i) [+ 1 for the hole noise]) at step i; */
+  unsigned long long noise_seed; /*   first_step = index of this call's first step in the whole chain (a loop cut into calls)    */
 } ivid_sample_plan;
 typedef struct {
   const float* y; const float* mask; const float* mask_rgb; const float* hole_noise;

@@ -76,7 +76,8 @@ class DdpmCoef(C.Structure):
 
 class SamplePlan(C.Structure):      # ivid_sample_plan
     _fields_ = [("kind", C.c_int), ("n_steps", C.c_int), ("hw", C.c_int), ("t_model", C.POINTER(C.c_longlong)),
-                ("coef", C.c_void_p), ("engine_of_step", C.POINTER(C.c_int))]
+                ("coef", C.c_void_p), ("engine_of_step", C.POINTER(C.c_int)), ("generate_noise", C.c_int), ("first_step", C.c_int),
+                ("noise_seed", C.c_ulonglong)]
 
 
 class SampleCond(C.Structure):      # ivid_sample_cond
@@ -140,6 +141,7 @@ SIGNATURES = {
     "ivid_copy": (i32, [vp, vp, i64, vp]),
     "ivid_nchw_to_nhwc": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ivid_stem_im2col": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ivid_randn": (i32, [C.c_ulonglong, C.c_ulonglong, vp, i64, vp]),
     "ivid_sample_scratch_bytes": (i64, [vp, i32, C.POINTER(SamplePlan), C.POINTER(SampleCond)]),
     "ivid_sample": (i32, [vp, i32, C.POINTER(SamplePlan), vp, C.POINTER(SampleCond), vp, vp, vp, vp, i64, vp]),
     "ivid_ddim_step": (i32, [vp, vp, vp, C.POINTER(DdimCoef), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

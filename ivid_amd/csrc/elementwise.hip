@@ -255,6 +255,54 @@ extern "C" int ivid_copy(void* dst, const void* src, long long bytes, void* stre
   return ivid_check_launch("copy");
 }
 
+// ---- counter-based Gaussian noise (ivid_randn): Philox4x32-10 (Salmon et al., SC'11) + Box-Muller ----
+// Output block j (values 4j .. 4j+3) of stream `sid` under key `seed` = Philox(counter = (j_lo, j_hi, sid_lo, sid_hi), key = (seed_lo,
+// seed_hi)); a 32-bit word r becomes the uniform u = ((r >> 8) + 0.5) * 2^-24 in (0, 1) -- exact in fp32 --, pairs (u0, u1) become
+// sqrt(-2 ln u0) * (cos, sin)(2 pi u1).  A value depends on (seed, sid, index) alone: any launch shape, any rank, any order.
+namespace {
+__device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void randn_kernel(unsigned long long seed, unsigned long long sid, float* __restrict__ out, long long n) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (4 * j >= n) return;
+  uint32_t c[4] = {(uint32_t)j, (uint32_t)((unsigned long long)j >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u0 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u1 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u0));
+    float sn, cs;
+    sincospif(2.0f * u1, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+  if (4 * j + 4 <= n) {
+    *(f32x4*)(out + 4 * j) = f32x4{z[0], z[1], z[2], z[3]};
+  } else {
+    for (int e = 0; 4 * j + e < n; ++e) out[4 * j + e] = z[e];
+  }
+}
+}  // namespace
+
+extern "C" int ivid_randn(unsigned long long seed, unsigned long long stream_id, float* out, long long n, void* stream) {
+  if (!out || n < 0 || ((uintptr_t)out & 15)) return ivid_set_error("randn: out must be a 16-byte aligned device pointer", hipSuccess);
+  if (n == 0) return 0;
+  const long long blocks = (n + 1023) / 1024;
+  if (blocks >= (1ll << 31)) return ivid_set_error("randn: n too large", hipSuccess);
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seed, stream_id, out, n);
+  return ivid_check_launch("randn");
+}
+
 extern "C" int ivid_silu_f32(const float* x, float* y, long long n, void* stream) {
   hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   return ivid_check_launch("silu");

@@ -355,7 +355,7 @@ extern "C" long long ivid_sample_scratch_bytes(void* const* engines, int n_engin
   if (!plan || plan->n_steps <= 0) { ivid_set_error("sample: empty plan", hipSuccess); return -1; }
   if (sample_geom(engines, n_engines, plan->hw, &g) != 0) return -1;
   const long long img = (long long)g.B * 4 * g.HW * 4;
-  return align256((long long)plan->n_steps * g.B * 8) + 2 * align256(img) +
+  return align256((long long)plan->n_steps * g.B * 8) + (plan->generate_noise ? 4 : 2) * align256(img) +
          ((cond && (cond->y || cond->sr_y)) ? align256((long long)g.B * g.cin * g.HW * 4) : 0);
 }
 
@@ -373,7 +373,9 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
   const bool inpaint = cond && cond->y;
   const bool superres = cond && cond->sr_y;
   if (inpaint && superres) return ivid_set_error("sample: y and sr_y are two different frameworks' conditioning", hipSuccess);
-  if (inpaint && (!cond->mask || !cond->hole_noise)) return ivid_set_error("sample: inpainting needs y, mask and the hole noise", hipSuccess);
+  const bool gen = plan->generate_noise != 0;
+  if (inpaint && (!cond->mask || !(cond->hole_noise || gen))) return ivid_set_error("sample: inpainting needs y, mask and the hole noise", hipSuccess);
+  if (gen && plan->first_step < 0) return ivid_set_error("sample: first_step < 0", hipSuccess);
   int S = 0;
   if (superres) {
     while ((long long)S * S < g.HW) ++S;
@@ -390,7 +392,7 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
     const int e = plan->engine_of_step ? plan->engine_of_step[i] : 0;
     if (e < 0 || e >= n_engines) return ivid_set_error("sample: engine_of_step out of range", hipSuccess);
     const bool noisy = kd ? kd[i].sigma != 0.f : kp[i].std != 0.f;
-    if (noisy && !step_noise) return ivid_set_error("sample: a step draws noise but step_noise is NULL", hipSuccess);
+    if (noisy && !step_noise && !gen) return ivid_set_error("sample: a step draws noise but step_noise is NULL", hipSuccess);
     if (kd && ((kd[i].replace_rgb_w >= 0.f && !(cond && cond->rgb && cond->rgb_mask)) ||
                (kd[i].replace_depth_w >= 0.f && !(cond && cond->depth && cond->depth_mask)) ||
                (kd[i].constrain_w >= 0.f && !(cond && cond->convex))))
@@ -402,6 +404,8 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
   long long* t_dev = (long long*)sp;  sp += align256((long long)plan->n_steps * g.B * 8);
   float* x_alt = (float*)sp;          sp += align256(img_elems * 4);
   float* x0_own = (float*)sp;         sp += align256(img_elems * 4);
+  float* gen_step = gen ? (float*)sp : nullptr;   sp += gen ? align256(img_elems * 4) : 0;
+  float* gen_hole = gen ? (float*)sp : nullptr;   sp += gen ? align256(img_elems * 4) : 0;
   float* cond_in = (inpaint || superres) ? (float*)sp : nullptr;
   float* cur = x;
   float* nxt = x_alt;
@@ -412,7 +416,11 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
     hipLaunchKernelGGL(fill_i64_kernel, dim3((g.B + 255) / 256), dim3(256), 0, s, ti, plan->t_model[i], g.B);
     const float* model_in = cur;
     if (inpaint) {
-      const float* hn = cond->hole_noise + (long long)i * img_elems;   // per step: rgb noise [B,3,HW], then depth noise [B,1,HW]
+      const float* hn = cond->hole_noise ? cond->hole_noise + (long long)i * img_elems : gen_hole;   // rgb noise [B,3,HW], then depth noise [B,1,HW]
+      if (!cond->hole_noise) {
+        st = ivid_randn(plan->noise_seed, 2ull * (unsigned long long)(plan->first_step + i) + 1, gen_hole, img_elems, stream);
+        if (st != 0) return st;
+      }
       st = ivid_inpaint_cond(cur, cond->y, cond->mask, cond->mask_rgb, hn, hn + (long long)g.B * 3 * g.HW, cond_in, g.B, g.HW, stream);
       if (st != 0) return st;
       model_in = cond_in;
@@ -426,6 +434,11 @@ extern "C" int ivid_sample(void* const* engines, int n_engines, const ivid_sampl
     const float* eps_c = p->out;
     const float* eps_u = g.stacked ? p->out + img_elems : nullptr;
     const float* nz = step_noise ? step_noise + (long long)i * img_elems : nullptr;
+    if (!step_noise && gen && (kd ? kd[i].sigma != 0.f : kp[i].std != 0.f)) {
+      st = ivid_randn(plan->noise_seed, 2ull * (unsigned long long)(plan->first_step + i), gen_step, img_elems, stream);
+      if (st != 0) return st;
+      nz = gen_step;
+    }
     if (kd) {
       st = ivid_ddim_step(cur, eps_c, eps_u, &kd[i], cond ? cond->rgb : nullptr, cond ? cond->rgb_mask : nullptr,
                           cond ? cond->depth : nullptr, cond ? cond->depth_mask : nullptr, cond ? cond->convex : nullptr,

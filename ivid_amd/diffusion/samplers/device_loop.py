@@ -8,6 +8,9 @@ What it covers is what the sampling drivers issue (inference/sample.py:75-139): 
 itself, InpaintCFG with `replace_rgb` / `replace_depth` / `constrain_depth`, SuperResCFG on a low-resolution `y`; anything else (a foreign framework or backbone, a
 guidance strength <= 0 with classes, further framework arguments) raises NotImplementedError — the caller keeps the host loop
 for those.  Intermediates are not kept: `pred_x_t` comes back empty and `pred_x_0` holds the last step's prediction.
+`device_noise_seed=<int>`: every draw of the loop (step noise, InpaintCFG's hole noise) comes from the library's counter-based
+generator (`ivid_randn`: stream 2 * step [+ 1] under that seed) instead of torch's -- no noise buffers, the same chain whatever the
+loop is cut into; x_T is still the caller's.
 """
 import ctypes as C
 
@@ -34,6 +37,10 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
     bb = _backbone_of(fw)
     kwargs = dict(kwargs)
     injected = kwargs.pop("noise_fn", None)
+    dev_seed = kwargs.pop("device_noise_seed", None)
+    chunk = int(kwargs.pop("device_loop_chunk", chunk))
+    if dev_seed is not None and injected is not None:
+        raise ValueError("device_loop: noise_fn and device_noise_seed exclude each other")
     noise_fn = injected or (lambda shape: default_noise(shape, img.device))
     strength = kwargs.pop("strength", 3.0 if type(fw) in (ClassifierFreeGuidance, InpaintCFG, SuperResCFG) else 0.0)
     inpaint = type(fw) is InpaintCFG
@@ -114,10 +121,11 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
         eng = (C.c_int * n)(*[order.index(k) for k in tiers[s0:s0 + n]])
         # noise in the host loop's draw order: per step [hole rgb, hole depth,] step noise (drawn whenever the host loop draws it)
         # (the kernel takes a step's hole noise as two dense tensors: rgb [B,3,HW], then depth [B,1,HW])
-        hole = torch.empty(n, b * 4 * hw, dtype=torch.float32, device=x.device) if inpaint else None
-        any_noise = any(d for (_, _, d) in part)
+        gen = dev_seed is not None
+        hole = torch.empty(n, b * 4 * hw, dtype=torch.float32, device=x.device) if (inpaint and not gen) else None
+        any_noise = any(d for (_, _, d) in part) and not gen
         stepn = torch.empty(n, b, 4, h, w, dtype=torch.float32, device=x.device) if any_noise else None
-        for i, (_, _, draws) in enumerate(part):
+        for i, (_, _, draws) in enumerate(part if not gen else ()):
             if inpaint:
                 hole[i, :b * 3 * hw].view(b, 3, h, w).copy_(noise_fn((b, 3, h, w)))
                 hole[i, b * 3 * hw:].view(b, 1, h, w).copy_(noise_fn((b, 1, h, w)))
@@ -126,8 +134,8 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
                 if draws:
                     stepn[i] = z
         if inpaint:
-            cond.hole_noise = hole.data_ptr()
-        plan = _lib.SamplePlan(kind, n, hw, tm, C.cast(coefs, C.c_void_p), eng)
+            cond.hole_noise = hole.data_ptr() if hole is not None else None
+        plan = _lib.SamplePlan(kind, n, hw, tm, C.cast(coefs, C.c_void_p), eng, int(gen), s0, int(dev_seed) & (2 ** 64 - 1) if gen else 0)
         use_cond = C.byref(cond) if (inpaint or cond.sr_y or w_rgb >= 0 or w_dep >= 0) else None
         need = _lib.load().ivid_sample_scratch_bytes(handles, len(plans), C.byref(plan), use_cond)
         if need < 0:
@@ -143,10 +151,10 @@ def run(sampler, kind, img, steps, classes, kwargs, chunk=64):
     return AttrDict({"samples": x, "pred_x_t": [], "pred_x_0": [x0]})
 
 
-def write_plan_file(path, kind, hw, batch, t_model, engine_of_step, coefs, classes=None, step_noise=None, n_engines=None):
+def write_plan_file(path, kind, hw, batch, t_model, engine_of_step, coefs, classes=None, step_noise=None, n_engines=None, noise_seed=None):
     """The host tables of one `ivid_sample` call as a file a C host reads (examples/sample_loop_host.c documents the layout):
     `coefs` = the samplers' `_coef(...)` structs in sampling order, `classes` an int64 tensor / sequence or None, `step_noise` a
-    float32 tensor [n_steps, batch, 4, H, W] or None."""
+    float32 tensor [n_steps, batch, 4, H, W] or None; `noise_seed` (instead of step_noise): the host draws with ivid_randn."""
     import struct
 
     import numpy as np
@@ -154,7 +162,10 @@ def write_plan_file(path, kind, hw, batch, t_model, engine_of_step, coefs, class
     assert len(engine_of_step) == n and len(coefs) == n
     ne = n_engines if n_engines is not None else max(engine_of_step) + 1
     with open(path, "wb") as f:
-        f.write(struct.pack("<8i", 0x50535649, kind, n, hw, batch, int(classes is not None), int(step_noise is not None), ne))
+        assert step_noise is None or noise_seed is None
+        f.write(struct.pack("<8i", 0x50535649, kind, n, hw, batch, int(classes is not None),
+                            2 if noise_seed is not None else int(step_noise is not None), ne))
+        f.write(struct.pack("<Q", int(noise_seed or 0) & (2 ** 64 - 1)))
         f.write(np.asarray([int(t) for t in t_model], dtype="<i8").tobytes())
         f.write(np.asarray([int(e) for e in engine_of_step], dtype="<i4").tobytes())
         for k in coefs:

@@ -573,12 +573,16 @@ def test_sample_plan_file_layout_matches_what_the_c_host_parses(tmp_path):
     path = tmp_path / "plan.bin"
     device_loop.write_plan_file(str(path), _lib.SAMPLE_DDIM, hw, b, [899, 499, 99], [0, 1, 2], coefs, classes=torch.tensor([5, 7]), step_noise=noise)
     blob = path.read_bytes()
-    assert struct.unpack("<8i", blob[:32]) == (0x50535649, 0, n, hw, b, 1, 1, 3)
-    assert len(blob) == 32 + 8 * n + 4 * n + 44 * n + 8 * b + 4 * n * b * 4 * hw
-    off = 32
+    assert struct.unpack("<8i", blob[:32]) == (0x50535649, 0, n, hw, b, 1, 1, 3) and struct.unpack("<Q", blob[32:40]) == (0,)
+    assert len(blob) == 40 + 8 * n + 4 * n + 44 * n + 8 * b + 4 * n * b * 4 * hw
+    off = 40
     assert list(np.frombuffer(blob, "<i8", n, off)) == [899, 499, 99]; off += 8 * n
     assert list(np.frombuffer(blob, "<i4", n, off)) == [0, 1, 2]; off += 4 * n
     k1 = _lib.DdimCoef.from_buffer_copy(blob[off + 44:off + 88])
     assert (k1.sigma, k1.cfg_strength, k1.clip_denoised) == (0.25, 3.0, 1); off += 44 * n
     assert list(np.frombuffer(blob, "<i8", b, off)) == [5, 7]; off += 8 * b
     assert np.array_equal(np.frombuffer(blob, "<f4", -1, off), noise.numpy().ravel())
+    device_loop.write_plan_file(str(path), _lib.SAMPLE_DDIM, hw, b, [899, 499, 99], [0, 1, 2], coefs, noise_seed=2 ** 63 + 5)
+    blob = path.read_bytes()
+    assert struct.unpack("<8i", blob[:32])[5:7] == (0, 2) and struct.unpack("<Q", blob[32:40]) == (2 ** 63 + 5,)
+    assert len(blob) == 40 + 8 * n + 4 * n + 44 * n

@@ -186,3 +186,19 @@ def test_teacher_forced_steps_golden_is_consistent_with_the_chain_golden():
     um = lambda a, b, c: adm_oracle.unet_forward(sd, C.LARGE128, a, b, c)
     eps = sampler_oracle.cfg_eps(um, x, t, cls[:1], 0.5)
     assert C.rel_l2(eps, g["eps_step49"][:1]) < 1e-5
+
+
+def test_philox_oracle_reproduces_the_published_known_answer_vectors():
+    """oracle/philox_oracle.py (the checker of ivid_randn) against the Random123 known-answer vectors of Philox4x32-10
+    (Salmon et al., SC'11, kat_vectors): zero, all-ones and the pi-digits counter / key."""
+    import numpy as np
+    from oracle import philox_oracle as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(np.array(ctr, dtype=np.uint32), key)
+        assert tuple(int(v) for v in got) == want
+    z = P.randn(1234, 5, 1 << 18).astype(np.float64)
+    assert abs(z.mean()) < 6e-3 and abs(z.var() - 1) < 1e-2 and abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3) < 5e-2
+    assert not np.array_equal(P.randn(1234, 5, 64), P.randn(1234, 6, 64)) and not np.array_equal(P.randn(1234, 5, 64), P.randn(1235, 5, 64))

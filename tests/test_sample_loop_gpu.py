@@ -181,6 +181,12 @@ def test_c_host_samples_a_guided_ddim_chain_from_engine_files_without_python(tmp
                                 [order.index(k) for k in tiers],
                                 [smp._coef(t, tp, 0.0, strength, False, -1.0, -1.0, -1.0) for t, tp in pairs], classes=cls)
     xT.cpu().numpy().tofile(tmp_path / "xT.bin")
+    # the same schedule with eta = 0.5 and the library's own noise (the plan file carries the seed, no noise tensor)
+    want_eta = smp.sample(bs, noise=xT, classes=cls, steps=steps, strength=strength, eta=0.5, verbose=False, device_loop=True,
+                          device_noise_seed=11).samples.cpu().numpy()
+    device_loop.write_plan_file(str(tmp_path / "plan_eta.bin"), _lib.SAMPLE_DDIM, S * S, bs, [t - 1 for t, _ in pairs],
+                                [order.index(k) for k in tiers],
+                                [smp._coef(t, tp, 0.5, strength, False, -1.0, -1.0, -1.0) for t, tp in pairs], classes=cls, noise_seed=11)
     del m, fw, smp
     torch.cuda.synchronize()
     r = subprocess.run([B.LOOP_BIN, str(tmp_path / "plan.bin"), str(tmp_path / "xT.bin"), str(tmp_path / "out.bin")] + engines,
@@ -189,6 +195,11 @@ def test_c_host_samples_a_guided_ddim_chain_from_engine_files_without_python(tmp
     assert "one call" in r.stdout
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32).reshape(want.shape)
     assert np.array_equal(got, want)
+    r = subprocess.run([B.LOOP_BIN, str(tmp_path / "plan_eta.bin"), str(tmp_path / "xT.bin"), str(tmp_path / "out_eta.bin")] + engines,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "out_eta.bin", dtype=np.float32).reshape(want_eta.shape), want_eta)
+    assert not np.array_equal(want_eta, want)
     # an engine count that does not match the plan is refused by the host
     r = subprocess.run([B.LOOP_BIN, str(tmp_path / "plan.bin"), str(tmp_path / "xT.bin"), str(tmp_path / "o2.bin")] + engines[:2],
                        capture_output=True, text=True, timeout=600)
@@ -232,3 +243,72 @@ def test_superres_chain_device_loop_is_bit_identical_and_matches_the_reference_g
         outs.append(super_resolve(fw, low, classes=cls2, steps=4, strength=3.0, noise_fn=_cpu_noise_fn()))
     assert torch.equal(outs[0], outs[1])
     assert C.rel_l2(outs[1].cpu(), g["samples"]) < 1e-3
+
+
+def test_ivid_randn_matches_the_philox_oracle_and_is_a_function_of_seed_stream_and_index():
+    from ivid_amd import _lib
+    from oracle import philox_oracle as P
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, sid, n in ((0, 0, 4096), (1234, 5, 1003), (2 ** 63 + 17, 2 ** 40 + 3, 8190)):
+        out = torch.full((n + 8,), 7.0, device="cuda")
+        _lib.check(lib.ivid_randn(seed, sid, out.data_ptr(), n, st), "randn")
+        got = out.cpu().numpy()
+        assert np.all(got[n:] == 7.0)                                    # the tail of a partial block is not overrun
+        ref = P.randn(seed, sid, n)
+        assert np.abs(got[:n] - ref).max() < 4e-6, float(np.abs(got[:n] - ref).max())
+    big = torch.empty(1 << 22, device="cuda")
+    _lib.check(lib.ivid_randn(99, 1, big.data_ptr(), big.numel(), st), "randn")
+    z = big.double()
+    assert abs(float(z.mean())) < 2e-3 and abs(float(z.var()) - 1) < 3e-3 and abs(float(((z - z.mean()) ** 4).mean() / z.var() ** 2) - 3) < 2e-2
+    # a prefix of a longer draw is the shorter draw (index-addressed), other streams / seeds differ
+    small = torch.empty(1024, device="cuda")
+    _lib.check(lib.ivid_randn(99, 1, small.data_ptr(), 1024, st), "randn")
+    assert torch.equal(small, big[:1024])
+    _lib.check(lib.ivid_randn(99, 2, small.data_ptr(), 1024, st), "randn")
+    assert not torch.equal(small, big[:1024])
+    assert lib.ivid_randn(1, 1, big.data_ptr() + 4, 16, st) != 0             # misaligned output is refused
+
+
+def test_device_loop_with_library_noise_is_reproducible_and_independent_of_how_the_loop_is_cut():
+    """`device_noise_seed`: every draw (DDPM step noise; InpaintCFG hole noise + DDIM eta noise) from ivid_randn streams addressed by
+    the GLOBAL step index -- the same chain whether the 100 steps go in one call, in calls of 64 + 36 or of 7."""
+    from ivid_amd.diffusion import frameworks, samplers
+    g = C.load_golden("mini_ddpm")
+    xT = torch.from_numpy(g["x_T"]).cuda()
+    outs = []
+    for chunk in (128, 64, 7, 64):
+        m, _ = build(C.MINI_UNCLASS, 1, "fp32")
+        fw = frameworks.GaussianDiffusion(m, timesteps=100, beta_schedule="linear")
+        res = samplers.DdpmSampler(fw).sample(2, noise=xT, verbose=False, device_loop=True, device_noise_seed=4242, device_loop_chunk=chunk)
+        outs.append(res.samples)
+    assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.isfinite(outs[0]).all()
+    m, _ = build(C.MINI_UNCLASS, 1, "fp32")
+    fw = frameworks.GaussianDiffusion(m, timesteps=100, beta_schedule="linear")
+    other = samplers.DdpmSampler(fw).sample(2, noise=xT, verbose=False, device_loop=True, device_noise_seed=4243).samples
+    assert not torch.equal(other, outs[0])
+    # the noise the chain used IS the documented stream: replaying it through noise_fn on the host loop gives the same samples
+    from ivid_amd import _lib
+    lib = _lib.load()
+    step = [0]
+
+    def replay(shape):
+        z = torch.empty(shape, device="cuda")
+        _lib.check(lib.ivid_randn(4242, 2 * step[0], z.data_ptr(), z.numel(), torch.cuda.current_stream().cuda_stream), "randn")
+        step[0] += 1
+        return z
+    m, _ = build(C.MINI_UNCLASS, 1, "fp32")
+    fw = frameworks.GaussianDiffusion(m, timesteps=100, beta_schedule="linear")
+    host = samplers.DdpmSampler(fw).sample(2, noise=xT, verbose=False, noise_fn=replay).samples
+    assert torch.equal(host, outs[0])
+    # InpaintCFG: hole noise on stream 2 * step + 1
+    gi = C.load_golden("mini_ddim_inpaint")
+    T = lambda k: torch.from_numpy(gi[k]).cuda()
+    outs = []
+    for chunk in (64, 3):
+        mc, _ = build(C.MINI_COND, 2, "fp32")
+        fc = frameworks.InpaintCFG(mc, timesteps=1000, beta_schedule="linear", p_uncond=0.1, p_uncond_img=0.0)
+        outs.append(samplers.DdimSampler(fc).sample(2, noise=T("x_T"), classes=T("classes"), steps=8, strength=3.0, eta=0.5, verbose=False,
+                                                    y=T("y"), mask=T("mask"), mask_rgb=T("mask_rgb"), device_loop=True, device_noise_seed=7,
+                                                    device_loop_chunk=chunk).samples)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
